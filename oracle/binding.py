@@ -1,0 +1,187 @@
+"""ctypes binding of the CPU oracle (oracle/se_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under supereight_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS: dict = {}
+
+c_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+c_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+c_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+c_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+c_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+c_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def build(native: bool = False, force: bool = False) -> str:
+    """(Re)build the oracle shared library with oracle/Makefile; returns its path."""
+    out = "libse_oracle_native.so" if native else "libse_oracle.so"
+    path = os.path.join(_HERE, out)
+    src = os.path.join(_HERE, "se_oracle.cpp")
+    stale = (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src)
+    if force or stale:
+        args = ["make", "-C", _HERE, f"OUT={out}"] + (["ARCH=native"] if native else [])
+        if force:
+            args.insert(1, "-B")
+        subprocess.run(args, check=True, capture_output=True)
+    return path
+
+
+def _declare(lib):
+    u64, i32, f32, vp = C.c_uint64, C.c_int, C.c_float, C.c_void_p
+    sig = {
+        "so_compute_morton": (u64, [u64, u64, u64]),
+        "so_unpack_morton": (None, [u64, c_i32p]),
+        "so_mask": (u64, [i32]),
+        "so_encode": (u64, [i32, i32, i32, i32, i32]),
+        "so_decode": (None, [u64, c_i32p]),
+        "so_parent": (u64, [u64, i32]),
+        "so_child_id": (i32, [u64, i32, i32]),
+        "so_descendant": (i32, [u64, u64, i32]),
+        "so_far_corner": (None, [u64, i32, i32, c_i32p]),
+        "so_face_neighbour": (None, [u64, C.c_uint, C.c_uint, C.c_uint, c_i32p]),
+        "so_exterior_neighbours": (None, [c_u64p, u64, i32, i32]),
+        "so_siblings": (None, [c_u64p, u64, i32]),
+        "so_unique": (i32, [c_u64p, i32]),
+        "so_unique_u32": (i32, [c_u32p, i32]),
+        "so_filter_ancestors": (i32, [c_u64p, i32, i32]),
+        "so_unique_multiscale": (i32, [c_u64p, i32, C.c_uint]),
+        "so_filter_ancestors_u32": (i32, [c_u32p, i32, i32]),
+        "so_unique_multiscale_u32": (i32, [c_u32p, i32, C.c_uint]),
+        "so_cvt_i32": (i32, [f32]),
+        "so_bspline_lookup": (None, [c_f32p]),
+        "so_hnew": (f32, [f32]),
+        "so_update_logs": (f32, [f32, f32]),
+        "so_ft_create": (vp, [i32, f32, f32, f32]),
+        "so_ft_destroy": (None, [vp]),
+        "so_ft_hash": (u64, [vp, i32, i32, i32, i32]),
+        "so_ft_allocate": (i32, [vp, c_u64p, i32]),
+        "so_ft_get": (f32, [vp, i32, i32, i32]),
+        "so_ft_get_fine": (f32, [vp, i32, i32, i32]),
+        "so_ft_set": (None, [vp, i32, i32, i32, f32]),
+        "so_ft_fetch": (i32, [vp, i32, i32, i32, C.POINTER(u64), c_i32p]),
+        "so_ft_fetch_octant": (i32, [vp, i32, i32, i32, i32, C.POINTER(u64), C.POINTER(C.c_uint), C.POINTER(i32)]),
+        "so_ft_set_octant_value": (i32, [vp, i32, i32, i32, i32, i32, f32]),
+        "so_ft_insert": (i32, [vp, i32, i32, i32, i32, C.POINTER(u64), c_i32p, C.POINTER(i32)]),
+        "so_ft_counts": (None, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "so_ft_check_children_mask": (i32, [vp]),
+        "so_ft_node_sides": (None, [vp, c_u32p, c_u64p]),
+        "so_ft_gather": (None, [vp, i32, i32, i32, c_f32p]),
+        "so_ft_interp": (f32, [vp, f32, f32, f32]),
+        "so_ft_grad": (None, [vp, f32, f32, f32, c_f32p]),
+        "so_ft_ray_blocks": (i32, [vp, c_f32p, c_f32p, f32, f32, c_u64p, c_f32p, c_f32p, i32, c_f32p]),
+        "so_pipe_create": (vp, [i32, i32, f32, i32, i32]),
+        "so_pipe_destroy": (None, [vp]),
+        "so_pipe_count_stats": (None, [vp, i32]),
+        "so_pipe_integrate": (i32, [vp, c_f32p, c_f32p, c_f32p, C.c_uint, f32, C.c_uint]),
+        "so_pipe_raycast": (i32, [vp, c_f32p, c_f32p, f32, C.c_uint, c_f32p, c_f32p]),
+        "so_pipe_counts": (None, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "so_pipe_get_blocks": (None, [vp, c_i32p, c_f32p, c_f32p, c_u8p]),
+        "so_pipe_get_nodes": (None, [vp, c_u64p, c_u32p, c_f32p, c_f32p]),
+        "so_pipe_stats": (None, [vp, c_u64p]),
+        "so_pipe_timings": (None, [vp, c_f64p]),
+        "so_num_threads": (i32, []),
+        "so_set_num_threads": (None, [i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(native: bool = False):
+    key = "native" if native else "portable"
+    if key not in _LIBS:
+        try:
+            path = build(native=native)
+            lib = C.CDLL(path)
+        except (OSError, subprocess.CalledProcessError):
+            path = build(native=native, force=True)
+            lib = C.CDLL(path)
+        _LIBS[key] = _declare(lib)
+    return _LIBS[key]
+
+
+SDF, OFUSION = 0, 1
+STAT_NAMES = ("probes", "keys_emitted", "swept", "nodes", "gets", "interps", "grads", "hits", "oob")
+
+
+class OraclePipeline:
+    """The reference's DenseSLAMSystem::integration / ::raycasting on the CPU oracle."""
+
+    def __init__(self, field: int, size: int, dim: float, width: int, height: int, native: bool = False):
+        self.lib = load(native)
+        self.field, self.size, self.dim, self.W, self.H = field, size, float(dim), width, height
+        self.h = self.lib.so_pipe_create(field, size, dim, width, height)
+
+    def close(self):
+        if self.h:
+            self.lib.so_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count_stats(self, on: bool = True):
+        self.lib.so_pipe_count_stats(self.h, int(on))
+
+    def integrate(self, depth, pose, k, mu, frame, rate=1) -> bool:
+        from supereight_amd.synthetic import to_colmajor
+        d = np.ascontiguousarray(depth, dtype=np.float32).reshape(-1)
+        return bool(self.lib.so_pipe_integrate(self.h, d, to_colmajor(pose), np.asarray(k, np.float32), rate, mu, frame))
+
+    def raycast(self, pose, k, mu, frame):
+        from supereight_amd.synthetic import to_colmajor
+        v = np.zeros((self.H, self.W, 3), np.float32)
+        n = np.zeros((self.H, self.W, 3), np.float32)
+        ran = bool(self.lib.so_pipe_raycast(self.h, to_colmajor(pose), np.asarray(k, np.float32), mu, frame,
+                                            v.reshape(-1), n.reshape(-1)))
+        return ran, v, n
+
+    def counts(self):
+        nb, nn = C.c_int(), C.c_int()
+        self.lib.so_pipe_counts(self.h, C.byref(nb), C.byref(nn))
+        return nb.value, nn.value
+
+    def blocks(self):
+        """Blocks sorted by Morton key: coords[n,3], x[n,512], y[n,512], active[n]."""
+        nb, _ = self.counts()
+        coords = np.zeros((nb, 3), np.int32)
+        x = np.zeros((nb, 512), np.float32)
+        y = np.zeros((nb, 512), np.float32)
+        act = np.zeros(nb, np.uint8)
+        if nb:
+            self.lib.so_pipe_get_blocks(self.h, coords.reshape(-1), x.reshape(-1), y.reshape(-1), act)
+        return coords, x, y, act
+
+    def nodes(self):
+        _, nn = self.counts()
+        code = np.zeros(nn, np.uint64)
+        side = np.zeros(nn, np.uint32)
+        x = np.zeros((nn, 8), np.float32)
+        y = np.zeros((nn, 8), np.float32)
+        self.lib.so_pipe_get_nodes(self.h, code, side, x.reshape(-1), y.reshape(-1))
+        return code, side, x, y
+
+    def stats(self) -> dict:
+        out = np.zeros(9, np.uint64)
+        self.lib.so_pipe_stats(self.h, out)
+        return dict(zip(STAT_NAMES, (int(v) for v in out)))
+
+    def timings(self) -> dict:
+        out = np.zeros(4, np.float64)
+        self.lib.so_pipe_timings(self.h, out)
+        return dict(zip(("alloc_scan", "allocate", "sweep", "raycast"), out.tolist()))
