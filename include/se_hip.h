@@ -1,0 +1,136 @@
+/*
+ * se_hip.h -- C ABI of the MI355X (gfx950) dense-fusion hot path.
+ *
+ * This is the drop-in boundary for supereight's per-frame path
+ *     depth image -> voxel-block allocation -> TSDF / occupancy integration -> raycast
+ * i.e. what se_denseslam's DenseSLAMSystem::integration() / ::raycasting()
+ * (se_denseslam/src/DenseSLAMSystem.cpp:191-268) do on the host.  The reference has no FFI of
+ * its own (one process, header-only C++); each entry point below cites the reference
+ * interface it replaces.  POD arguments only: the same shared library serves the C++
+ * `DenseSLAMSystem` mirror (supereight_amd/csrc/DenseSLAMSystem.cpp), the ctypes binding
+ * (supereight_amd/pipeline.py) and any other FFI.
+ *
+ * Conventions
+ *   - every function returns an int status: >= 0 success (stage functions return 1 = "ran this
+ *     frame", 0 = "gated off", like the reference's bool), < 0 = SE_HIP_E_* ; nothing throws,
+ *     nothing calls exit(); se_hip_last_error() gives a message for the calling thread.
+ *   - 4x4 matrices are 16 floats in COLUMN-MAJOR order, i.e. Eigen::Matrix4f::data().
+ *   - k = (fx, fy, cx, cy) as Eigen::Vector4f k in the reference API.
+ *   - one handle <-> one caller thread at a time (the reference is not re-entrant either).
+ *   - all work is enqueued on one HIP stream per handle; calls that return data to the host
+ *     synchronise that stream, the others are asynchronous.
+ */
+#ifndef SE_HIP_H
+#define SE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SE_FIELD_TYPE of the reference (se_denseslam/include/se/volume_traits.hpp:41-72;
+ * se_denseslam/CMakeLists.txt:31-50 builds one library per field type) */
+#define SE_HIP_FIELD_SDF 0
+#define SE_HIP_FIELD_OFUSION 1
+
+#define SE_HIP_OK 0
+#define SE_HIP_E_INVALID (-1)   /* bad argument */
+#define SE_HIP_E_DEVICE (-2)    /* HIP runtime error */
+#define SE_HIP_E_CAPACITY (-3)  /* block / node / key-list pool exhausted */
+#define SE_HIP_E_NOGPU (-4)     /* no usable gfx950 device */
+
+typedef struct se_hip_pipeline se_hip_pipeline;
+
+/* Replaces the state set up by DenseSLAMSystem's constructor
+ * (se_denseslam/src/DenseSLAMSystem.cpp:65-126: computation_size_, volume_resolution_,
+ * volume_dimension_, discrete_vol_ptr_->init(res, dim)). */
+typedef struct se_hip_config {
+  int32_t width;             /* computation_size_.x() */
+  int32_t height;            /* computation_size_.y() */
+  int32_t volume_resolution; /* voxels per side; power of two in [64, 4096] */
+  float volume_dimension;    /* metres per side */
+  int32_t field_type;        /* SE_HIP_FIELD_* */
+  int32_t device;            /* HIP device ordinal */
+  int64_t max_blocks;        /* capacity of the voxel-block pool; 0 = default */
+  int32_t row_begin;         /* image rows [row_begin,row_end) this handle alloc-scans and */
+  int32_t row_end;           /*   raycasts (multi-GPU tile sharding); 0,0 = the whole image */
+} se_hip_config;
+
+int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out);
+int se_hip_destroy(se_hip_pipeline* p);
+const char* se_hip_last_error(void);
+/* free function synchroniseDevices() is declared but never defined in the reference
+ * (se_denseslam/include/se/DenseSLAMSystem.h:418); this is its body. */
+int se_hip_sync(se_hip_pipeline* p);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the handle's own. */
+int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
+
+/* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by
+ * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141). */
+int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m);
+/* mm2metersKernel fused into the upload (se_denseslam/src/preprocessing.cpp:161-188):
+ * uint16 millimetres of size (in_w, in_h), an integer multiple of the computation size. */
+int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_depth_mm, int32_t in_w, int32_t in_h);
+/* Zero-copy: integrate from a depth image already resident in HBM (width*height floats). */
+int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m);
+
+/* ---- bool DenseSLAMSystem::integration(const Vector4f& k, unsigned integration_rate, float mu,
+ *      unsigned frame)  (DenseSLAMSystem.h:193, DenseSLAMSystem.cpp:206-268); `pose` is the
+ *      member pose_ (camera -> world). */
+int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate, float mu,
+                     uint32_t frame);
+/* The same stage split for multi-GPU runs, so that the caller can put the RCCL allgather of the
+ * per-rank new-block key lists between the allocation scan and the sweep:
+ *   se_hip_alloc_scan     = buildAllocationList / buildOctantList + Octree::allocate for the keys
+ *                           found in this handle's image rows (kfusion/alloc_impl.hpp:54-118,
+ *                           bfusion/alloc_impl.hpp:56-129, se_core/include/se/octree.hpp:792-856)
+ *   se_hip_new_keys_device= the list this scan produced: uint64[0] = count, uint64[1..count] =
+ *                           keys in the reference's key format (octant_ops.hpp:49-53)
+ *   se_hip_alloc_commit   = Octree::allocate for `nlists` such lists gathered from other ranks
+ *                           (device memory, list i at device_lists + i*stride_words)
+ *   se_hip_integrate_sweep= projective_map (se_core/include/se/functors/projective_functor.hpp:139-176) */
+int se_hip_alloc_scan(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate, float mu,
+                      uint32_t frame);
+int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* capacity_words);
+int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words);
+int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate,
+                           float mu, uint32_t frame);
+
+/* ---- bool DenseSLAMSystem::raycasting(const Vector4f& k, float mu, unsigned frame)
+ *      (DenseSLAMSystem.h:212, DenseSLAMSystem.cpp:191-204) -> vertex_, normal_ */
+int se_hip_raycast(se_hip_pipeline* p, const float pose[16], const float k[4], float mu, uint32_t frame);
+/* vertex_ / normal_ : se::Image<Eigen::Vector3f>, packed 12 bytes per pixel, world frame */
+int se_hip_download_vertex_normal(se_hip_pipeline* p, float* host_vertex_xyz, float* host_normal_xyz);
+int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, float** device_normal_xyz);
+
+/* ---- map read-back: what getMap() exposes as a host se::Octree
+ *      (DenseSLAMSystem.h:295; se_core/include/se/octree.hpp:898-914 save layout). */
+int se_hip_counts(se_hip_pipeline* p, int32_t* n_blocks, int32_t* n_nodes);
+/* blocks sorted by key: coords[n][3] (min corner, voxels), x[n][512], y[n][512] (voxel index
+ * x + 8y + 64z, se_core/include/se/node.hpp:139-144), active[n] */
+int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float* y, uint8_t* active);
+/* internal nodes sorted by key: code[n] (key = code|level), side[n], x[n][8], y[n][8] (value_[8]) */
+int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, float* x, float* y);
+
+/* ---- measurement (replaces TICK()/TOCK() + PerfStats, se_shared/timings.h:7-15) */
+#define SE_HIP_K_ALLOC_SCAN 0
+#define SE_HIP_K_ALLOC_COMMIT 1
+#define SE_HIP_K_INTEGRATE_BLOCKS 2
+#define SE_HIP_K_INTEGRATE_NODES 3
+#define SE_HIP_K_RAYCAST 4
+#define SE_HIP_K_COUNT 5
+/* HIP-event timing of every kernel launch on the handle's stream (off by default). */
+int se_hip_enable_timing(se_hip_pipeline* p, int32_t on);
+/* sum of launch durations [ms] and number of launches per kernel since the last reset */
+int se_hip_get_timings(se_hip_pipeline* p, double ms_sum[SE_HIP_K_COUNT], int64_t launches[SE_HIP_K_COUNT], int32_t reset);
+/* Work counters behind the algorithmic-bytes figures of the roofline (instrumented kernel
+ * variants, slower; off by default): out[0..7] = alloc probes, new keys, swept blocks, nodes,
+ * get calls, interp calls, grad calls, ray hits -- accumulated since enabled / last read. */
+int se_hip_enable_stats(se_hip_pipeline* p, int32_t on);
+int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[8], int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE_HIP_H */

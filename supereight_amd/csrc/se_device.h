@@ -1,0 +1,129 @@
+// Device-side data layout and arithmetic helpers of the gfx950 dense-fusion path.
+//
+// HBM layout (one replica per GPU):
+//   tab[]      dense direct-mapped index pyramid: for every octree level l in [1, leaf] one
+//              (2^l)^3 uint32 grid, entry = 0 (absent) | id+1 | SE_PENDING (being created in the
+//              running alloc kernel).  Replaces the pointer octree of
+//              se_core/include/se/octree.hpp (fetch / fetch_octant / children walk).
+//   vx[], vy[] SoA voxel planes, 512 consecutive floats per block, voxel index x + 8y + 64z
+//              (se_core/include/se/node.hpp:139-144).  SDF: x = tsdf, y = weight.
+//              OFusion: x = log-odds, y = last-update time (the reference stores y as double;
+//              every value it ever holds is a float, so float storage is lossless).
+//   bpos[]     packed block position in block units (x | y<<10 | z<<20), bactive[] the
+//              VoxelBlock::active_ flag.
+//   nx[], ny[] Node::value_[8] of internal nodes, npos[]/nlevel[] their position and level.
+//
+// Arithmetic contract: IEEE-754 binary32, the operation order of the reference's source
+// text, no FMA contraction (the library is built with -ffp-contract=off), correctly rounded
+// division and sqrt (hipcc default), denormals preserved.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SE_PENDING 0xFFFFFFFFu
+#define SE_MAX_LEVELS 12
+
+enum { C_BLOCKS = 0, C_NODES = 1, C_OVERFLOW = 2, C_COUNT = 8 };
+enum { S_PROBES = 0, S_NEWKEYS = 1, S_SWEPT = 2, S_NODES = 3, S_GETS = 4, S_INTERPS = 5, S_GRADS = 6, S_HITS = 7, S_COUNT = 8 };
+
+struct DevMap {
+  uint32_t* tab;
+  uint32_t off[SE_MAX_LEVELS];
+  int size, max_level, leaf_level;
+  float dim;
+  float* vx;
+  float* vy;
+  uint32_t* bpos;
+  uint8_t* bactive;
+  float* nx;
+  float* ny;
+  uint32_t* npos;
+  uint8_t* nlevel;
+  uint32_t* ctr;
+  unsigned long long* stats;
+  unsigned long long* newkeys;  // [0] = count, [1..] keys
+  unsigned long long cap_keys;
+  uint32_t cap_blocks, cap_nodes;
+  float init_x, init_y, empty_x;
+};
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 f3_add(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 f3_sub(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 f3_scale(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ f3 f3_scale_r(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 f3_div(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ f3 f3_mul(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ float f3_sqnorm(f3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
+// Eigen's normalized(): v / sqrt(squaredNorm) when squaredNorm > 0
+__device__ __forceinline__ f3 f3_normalized(f3 a) {
+  const float z = f3_sqnorm(a);
+  if (z > 0.f) return f3_div(a, sqrtf(z));
+  return a;
+}
+// 3x3 (row-major r[9]) * vector, accumulation left to right
+__device__ __forceinline__ f3 m3_mul(const float* r, f3 p) {
+  f3 o;
+  o.x = (r[0] * p.x + r[1] * p.y) + r[2] * p.z;
+  o.y = (r[3] * p.x + r[4] * p.y) + r[5] * p.z;
+  o.z = (r[6] * p.x + r[7] * p.y) + r[8] * p.z;
+  return o;
+}
+// 3x4 (row-major a[12]) * homogeneous point
+__device__ __forceinline__ f3 m34_mul_h(const float* a, f3 p) {
+  f3 o;
+  o.x = ((a[0] * p.x + a[1] * p.y) + a[2] * p.z) + a[3] * 1.f;
+  o.y = ((a[4] * p.x + a[5] * p.y) + a[6] * p.z) + a[7] * 1.f;
+  o.z = ((a[8] * p.x + a[9] * p.y) + a[10] * p.z) + a[11] * 1.f;
+  return o;
+}
+// float -> int32 as x86 cvttss2si does it (what the reference's casts compile to)
+__device__ __forceinline__ int cvt_i32(float f) {
+  if (!(f > -2147483904.f && f < 2147483648.f)) return (int)0x80000000;
+  return (int)f;
+}
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)
+__device__ __forceinline__ float clampf(float f, float a, float b) { return std_max(a, std_min(f, b)); }
+__device__ __forceinline__ float sqf(float a) { return a * a; }
+
+__device__ __forceinline__ uint32_t pack_pos(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
+__device__ __forceinline__ uint32_t tab_index(const DevMap& m, int l, int x, int y, int z) {
+  return m.off[l] + (((((uint32_t)z << l) | (uint32_t)y) << l) | (uint32_t)x);
+}
+__device__ __forceinline__ uint32_t tab_index_packed(const DevMap& m, int l, uint32_t p) {
+  return m.off[l] + (((((p >> 20) & 1023u) << l) | ((p >> 10) & 1023u)) << l | (p & 1023u));
+}
+__device__ __forceinline__ bool in_volume(const DevMap& m, int x, int y, int z) {
+  return (unsigned)x < (unsigned)m.size && (unsigned)y < (unsigned)m.size && (unsigned)z < (unsigned)m.size;
+}
+
+// 21-bit-per-axis Morton spread (se_core/include/se/utils/morton_utils.hpp:37-45); only used when a
+// key leaves the device-side index (new-key lists, downloads).
+__host__ __device__ __forceinline__ unsigned long long se_expand21(unsigned long long v) {
+  unsigned long long x = v & 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__host__ __device__ __forceinline__ unsigned long long se_compact21(unsigned long long v) {
+  unsigned long long x = v & 0x1249249249249249ull;
+  x = (x | x >> 2) & 0x10c30c30c30c30c3ull;
+  x = (x | x >> 4) & 0x100f00f00f00f00full;
+  x = (x | x >> 8) & 0x1f0000ff0000ffull;
+  x = (x | x >> 16) & 0x1f00000000ffffull;
+  x = (x | x >> 32) & 0x1fffffull;
+  return x;
+}
+// key of the octant at `level` whose position in units of its own side is (x,y,z):
+// morton(voxel coords) | level  (se_core/include/se/octant_ops.hpp:49-53)
+__host__ __device__ __forceinline__ unsigned long long se_make_key(int x, int y, int z, int level, int max_level) {
+  const int sh = max_level - level;
+  const unsigned long long code = se_expand21((unsigned long long)x << sh) | (se_expand21((unsigned long long)y << sh) << 1) |
+                                  (se_expand21((unsigned long long)z << sh) << 2);
+  return code | (unsigned long long)level;
+}

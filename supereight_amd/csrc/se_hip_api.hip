@@ -1,0 +1,614 @@
+// C ABI (include/se_hip.h) of the gfx950 dense-fusion path: handle management, per-frame
+// host-side matrix set-up (the few 4x4 products DenseSLAMSystem.cpp does before calling its
+// kernels) and kernel launches.  There is no CPU fallback: without a usable HIP device
+// se_hip_create() fails with SE_HIP_E_NOGPU.
+#include "../../include/se_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "se_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- host-side matrix helpers (row-major m[r][c]); same operation order as the kernels use
+struct M4 { float m[4][4]; };
+M4 from_colmajor(const float* p) {
+  M4 a;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) a.m[r][c] = p[c * 4 + r];
+  return a;
+}
+M4 mul(const M4& a, const M4& b) {
+  M4 c;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      c.m[i][j] = ((a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j]) + a.m[i][3] * b.m[3][j];
+  return c;
+}
+// getCameraMatrix / getInverseCameraMatrix (se_denseslam/include/se/commons.h:255-271)
+M4 camera_matrix(const float k[4]) { return {{{k[0], 0, k[2], 0}, {0, k[1], k[3], 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}}; }
+M4 inverse_camera_matrix(const float k[4]) {
+  return {{{1.0f / k[0], 0, -k[2] / k[0], 0}, {0, 1.0f / k[1], -k[3] / k[1], 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}};
+}
+void mul3(const float r[9], const float v[3], float out[3]) {
+  out[0] = (r[0] * v[0] + r[1] * v[1]) + r[2] * v[2];
+  out[1] = (r[3] * v[0] + r[4] * v[1]) + r[5] * v[2];
+  out[2] = (r[6] * v[0] + r[7] * v[1]) + r[8] * v[2];
+}
+
+struct TimedLaunch { int kernel; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct se_hip_pipeline {
+  se_hip_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DevMap map{};
+  int leaf_level = 0, max_level = 0;
+  size_t tab_entries = 0;
+  float* depth_own = nullptr;       // width*height floats
+  const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
+  unsigned short* depth_mm = nullptr;
+  size_t depth_mm_cap = 0;
+  float* vertex = nullptr;
+  float* normal = nullptr;
+  float* bspline = nullptr;
+  float* logodds = nullptr;
+  unsigned long long* chain = nullptr;  // 3 candidates for the keys[0] quirk
+  uint32_t* ctr_host = nullptr;         // pinned
+  bool timing = false, stats = false;
+  std::vector<TimedLaunch> pending;
+  std::vector<hipEvent_t> event_pool;
+  double ms_sum[SE_HIP_K_COUNT] = {0};
+  int64_t launches[SE_HIP_K_COUNT] = {0};
+  int row_begin = 0, row_end = 0;
+};
+
+namespace {
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+hipEvent_t get_event(se_hip_pipeline* p) {
+  if (!p->event_pool.empty()) { hipEvent_t e = p->event_pool.back(); p->event_pool.pop_back(); return e; }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+struct ScopedTimer {
+  se_hip_pipeline* p; int k; hipEvent_t a{}, b{};
+  ScopedTimer(se_hip_pipeline* p_, int k_) : p(p_), k(k_) {
+    if (p->timing) { a = get_event(p); b = get_event(p); hipEventRecord(a, p->stream); }
+  }
+  ~ScopedTimer() {
+    if (p->timing) { hipEventRecord(b, p->stream); p->pending.push_back({k, a, b}); }
+  }
+};
+void drain_timings(se_hip_pipeline* p) {
+  if (p->pending.empty()) return;
+  hipStreamSynchronize(p->stream);
+  for (auto& t : p->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) { p->ms_sum[t.kernel] += ms; p->launches[t.kernel]++; }
+    p->event_pool.push_back(t.start);
+    p->event_pool.push_back(t.stop);
+  }
+  p->pending.clear();
+}
+
+// bspline_lookup (se_denseslam/src/bfusion/bspline_lookup.cc:36-37): the reference's 1000 literals
+// are the cubic B-spline CDF at t_i = -3 + 6 i / 999 printed with 12 significant digits; they are
+// regenerated here (tests check the regeneration against the reference's literals).
+double bspline_cdf(double t) {
+  if (t >= -3.0 && t <= -1.0) return std::pow(3 + t, 3) / 48.0;
+  if (t > -1 && t <= 1) return 0.5 + (t * (3 + t) * (3 - t)) / 24.0;
+  if (t > 1 && t <= 3) return 1 - std::pow(3 - t, 3) / 48.0;
+  if (t > 3) return 1.0;
+  return 0.0;
+}
+void make_bspline(std::vector<float>& lut) {
+  lut.resize(1000);
+  for (int i = 0; i < 1000; ++i) {
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.12g", bspline_cdf(-3.0 + 6.0 * i / 999.0));
+    lut[i] = (float)std::strtod(buf, nullptr);
+  }
+}
+// updateLogs() of the reference calls the C library's log2f (se_denseslam/src/bfusion/mapping_impl.hpp:146-149).
+// HNew() only ever yields sample = Q1 - 0.5*Q2 with Q1, Q2 drawn from the 1000-entry table (or the
+// constants 0 and 1), so log2f(s / (1 - s)) after the [0.03, 0.97] clamp is tabulated here for every
+// index pair with the same C library call; the kernel then needs no transcendental at all.
+void make_logodds(const std::vector<float>& lut, std::vector<float>& tab) {
+  tab.resize((size_t)SE_LO_DIM * SE_LO_DIM);
+  auto q = [&](int i) { return i < 1000 ? lut[i] : (i == 1001 ? 1.f : 0.f); };
+  for (int i1 = 0; i1 < SE_LO_DIM; ++i1)
+    for (int i2 = 0; i2 < SE_LO_DIM; ++i2) {
+      float sample = q(i1) - q(i2) * 0.5f;
+      sample = std::max(0.03f, std::min(sample, 0.97f));
+      tab[(size_t)i1 * SE_LO_DIM + i2] = log2f(sample / (1.f - sample));
+    }
+}
+
+int check(se_hip_pipeline* p) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  hipError_t e = hipSetDevice(p->device);
+  if (e != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return SE_HIP_OK;
+}
+
+bool stage_runs_integration(uint32_t frame, uint32_t rate) { return ((frame % rate) == 0) || (frame <= 3); }
+
+int grid_for(size_t n, int wg, int cap) { size_t g = (n + wg - 1) / wg; if (g < 1) g = 1; if (g > (size_t)cap) g = cap; return (int)g; }
+
+}  // namespace
+
+extern "C" {
+
+const char* se_hip_last_error(void) { return g_err.c_str(); }
+
+int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
+  if (!cfg || !out) return fail(SE_HIP_E_INVALID, "null argument");
+  *out = nullptr;
+  const int N = cfg->volume_resolution;
+  if (cfg->width <= 0 || cfg->height <= 0) return fail(SE_HIP_E_INVALID, "bad image size");
+  if (N < 64 || N > 4096 || (N & (N - 1))) return fail(SE_HIP_E_INVALID, "volume_resolution must be a power of two in [64, 4096]");
+  if (!(cfg->volume_dimension > 0)) return fail(SE_HIP_E_INVALID, "volume_dimension must be positive");
+  if (cfg->field_type != SE_HIP_FIELD_SDF && cfg->field_type != SE_HIP_FIELD_OFUSION) return fail(SE_HIP_E_INVALID, "unknown field type");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SE_HIP_E_NOGPU, "no HIP device visible (this library has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(SE_HIP_E_INVALID, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(SE_HIP_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+  se_hip_pipeline* p = new se_hip_pipeline();
+  p->cfg = *cfg;
+  p->device = cfg->device;
+  p->row_begin = cfg->row_begin;
+  p->row_end = (cfg->row_end > cfg->row_begin) ? cfg->row_end : cfg->height;
+  if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
+  p->max_level = ilog2(N);
+  p->leaf_level = p->max_level - 3;
+  DevMap& m = p->map;
+  m.size = N; m.max_level = p->max_level; m.leaf_level = p->leaf_level; m.dim = cfg->volume_dimension;
+  size_t off = 0;
+  for (int l = 0; l < SE_MAX_LEVELS; ++l) m.off[l] = 0;
+  for (int l = 1; l <= p->leaf_level; ++l) { m.off[l] = (uint32_t)off; off += (size_t)1 << (3 * l); }
+  p->tab_entries = off;
+  const size_t cells = (size_t)1 << (3 * p->leaf_level);
+  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : std::min(cells, (size_t)1 << 21);
+  cap = std::min(cap, cells);
+  size_t capn = std::min(off - cells + 1, cap / 2 + 4096);  // internal nodes (+ root)
+  m.cap_blocks = (uint32_t)cap; m.cap_nodes = (uint32_t)capn;
+  m.cap_keys = cap + capn;
+  if (cfg->field_type == SE_HIP_FIELD_SDF) { m.init_x = 1.f; m.init_y = 0.f; m.empty_x = 1.f; }
+  else { m.init_x = 0.f; m.init_y = 0.f; m.empty_x = 0.f; }
+
+  auto bail = [&](hipError_t e, const char* what) { std::string msg = std::string(what) + ": " + hipGetErrorString(e); se_hip_destroy(p); return fail(SE_HIP_E_DEVICE, msg); };
+#define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) return bail(e_, "hipMalloc " #ptr); } while (0)
+  hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return bail(e, "hipStreamCreate");
+  p->own_stream = true;
+  ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
+  ALLOC(m.vx, cap * 512 * sizeof(float));
+  ALLOC(m.vy, cap * 512 * sizeof(float));
+  ALLOC(m.bpos, cap * sizeof(uint32_t));
+  ALLOC(m.bactive, cap);
+  ALLOC(m.nx, capn * 8 * sizeof(float));
+  ALLOC(m.ny, capn * 8 * sizeof(float));
+  ALLOC(m.npos, capn * sizeof(uint32_t));
+  ALLOC(m.nlevel, capn);
+  ALLOC(m.ctr, C_COUNT * sizeof(uint32_t));
+  ALLOC(m.stats, S_COUNT * sizeof(unsigned long long));
+  ALLOC(m.newkeys, (m.cap_keys + 1) * sizeof(unsigned long long));
+  ALLOC(p->depth_own, (size_t)cfg->width * cfg->height * sizeof(float));
+  ALLOC(p->vertex, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
+  ALLOC(p->normal, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
+  ALLOC(p->chain, 4 * sizeof(unsigned long long));
+  p->depth = p->depth_own;
+  e = hipHostMalloc((void**)&p->ctr_host, C_COUNT * sizeof(uint32_t));
+  if (e != hipSuccess) return bail(e, "hipHostMalloc");
+
+  hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.bpos, 0, cap * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.bactive, 0, cap, p->stream);
+  hipMemsetAsync(m.npos, 0, capn * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.nlevel, 0, capn, p->stream);
+  hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
+  hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), p->stream);
+  hipMemsetAsync(p->depth_own, 0, (size_t)cfg->width * cfg->height * sizeof(float), p->stream);
+  hipMemsetAsync(p->vertex, 0, (size_t)cfg->width * cfg->height * 3 * sizeof(float), p->stream);
+  hipMemsetAsync(p->normal, 0, (size_t)cfg->width * cfg->height * 3 * sizeof(float), p->stream);
+  // node 0 = root (Octree::init, se_core/include/se/octree.hpp:425-437): level 0, side = size
+  const uint32_t ctr0[C_COUNT] = {0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u};
+  hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, p->stream, m.vx, m.init_x, cap * 512);
+  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, p->stream, m.vy, m.init_y, cap * 512);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.nx, m.init_x, capn * 8);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.ny, m.init_y, capn * 8);
+  if (cfg->field_type == SE_HIP_FIELD_OFUSION) {
+    std::vector<float> lut, lo;
+    make_bspline(lut);
+    make_logodds(lut, lo);
+    ALLOC(p->bspline, lut.size() * sizeof(float));
+    ALLOC(p->logodds, lo.size() * sizeof(float));
+    hipMemcpy(p->bspline, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice);
+    hipMemcpy(p->logodds, lo.data(), lo.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
+#undef ALLOC
+  e = hipStreamSynchronize(p->stream);
+  if (e != hipSuccess) return bail(e, "initialisation");
+  *out = p;
+  return SE_HIP_OK;
+}
+
+int se_hip_destroy(se_hip_pipeline* p) {
+  if (!p) return SE_HIP_OK;
+  hipSetDevice(p->device);
+  if (p->stream) hipStreamSynchronize(p->stream);
+  for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+  for (auto& ev : p->event_pool) hipEventDestroy(ev);
+  DevMap& m = p->map;
+  void* ptrs[] = {m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, m.newkeys,
+                  p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain};
+  for (void* q : ptrs) if (q) hipFree(q);
+  if (p->ctr_host) hipHostFree(p->ctr_host);
+  if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
+  delete p;
+  return SE_HIP_OK;
+}
+
+int se_hip_sync(se_hip_pipeline* p) {
+  if (int r = check(p)) return r;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return SE_HIP_OK;
+}
+
+int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
+  if (int r = check(p)) return r;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  drain_timings(p);
+  if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
+  p->stream = (hipStream_t)hip_stream;
+  p->own_stream = false;
+  return SE_HIP_OK;
+}
+
+int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m) {
+  if (int r = check(p)) return r;
+  if (!host_depth_m) return fail(SE_HIP_E_INVALID, "null depth");
+  HIP_TRY(hipMemcpyAsync(p->depth_own, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), hipMemcpyHostToDevice, p->stream));
+  p->depth = p->depth_own;
+  return SE_HIP_OK;
+}
+
+int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t in_w, int32_t in_h) {
+  if (int r = check(p)) return r;
+  if (!host_mm) return fail(SE_HIP_E_INVALID, "null depth");
+  const int W = p->cfg.width, H = p->cfg.height;
+  // the reference prints "Invalid ratio." and exits (preprocessing.cpp:165-176); here it is an error code
+  if (in_w < W || in_h < H || in_w % W != 0 || in_h % H != 0 || in_w / W != in_h / H) return fail(SE_HIP_E_INVALID, "Invalid ratio.");
+  const size_t n = (size_t)in_w * in_h;
+  if (p->depth_mm_cap < n) {
+    if (p->depth_mm) hipFree(p->depth_mm);
+    p->depth_mm = nullptr; p->depth_mm_cap = 0;
+    HIP_TRY(hipMalloc((void**)&p->depth_mm, n * sizeof(unsigned short)));
+    p->depth_mm_cap = n;
+  }
+  HIP_TRY(hipMemcpyAsync(p->depth_mm, host_mm, n * sizeof(unsigned short), hipMemcpyHostToDevice, p->stream));
+  hipLaunchKernelGGL(k_mm2meters, dim3((W + 255) / 256, H), dim3(256), 0, p->stream, p->depth_own, W, H, p->depth_mm, in_w, in_w / W);
+  HIP_TRY(hipGetLastError());
+  p->depth = p->depth_own;
+  return SE_HIP_OK;
+}
+
+int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m) {
+  if (int r = check(p)) return r;
+  p->depth = device_depth_m ? device_depth_m : p->depth_own;
+  return SE_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------- integrate
+int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  if (int r = check(p)) return r;
+  if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!stage_runs_integration(frame, rate)) return 0;  // DenseSLAMSystem.cpp:209
+  const DevMap& m = p->map;
+  const M4 pose = from_colmajor(pose_cm);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  AllocArgs a{};
+  const float voxelsize = m.dim / (float)m.size;                  // DenseSLAMSystem.cpp:211
+  const M4 kPose = mul(pose, inverse_camera_matrix(k));           // alloc_impl.hpp:63-64 (K.inverse(): closed form)
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) a.kpose[i * 4 + j] = kPose.m[i][j];
+  a.cam[0] = pose.m[0][3]; a.cam[1] = pose.m[1][3]; a.cam[2] = pose.m[2][3];
+  a.band = sdf ? 2 * mu : 6 * mu;                                 // DenseSLAMSystem.cpp:223,228
+  a.voxel = voxelsize;
+  a.inv_voxel = sdf ? 1 / voxelsize : 1.f / voxelsize;
+  a.num_steps = (int)std::ceil(a.band * a.inv_voxel);
+  a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+  // step_to_depth (bfusion/alloc_impl.hpp:48-51) for the three step sizes of compute_stepsize
+  auto s2d = [&](float step) { return (int)(floorf(log2f(voxelsize / step)) + m.max_level); };
+  a.depth_fine = s2d(voxelsize); a.depth_mid = s2d(10.f * voxelsize); a.depth_coarse = s2d(30.f * voxelsize);
+  HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), p->stream));
+  const int npix = (p->row_end - p->row_begin) * p->cfg.width;
+  const dim3 grid((npix + SE_WG - 1) / SE_WG), block(SE_WG);
+  {
+    ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN);
+    if (sdf) {
+      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_sdf<true>, grid, block, 0, p->stream, m, p->depth, a);
+      else hipLaunchKernelGGL(k_alloc_scan_sdf<false>, grid, block, 0, p->stream, m, p->depth, a);
+    } else {
+      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, p->stream, m, p->depth, a);
+      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, p->stream, m, p->depth, a);
+    }
+  }
+  if (!sdf) {
+    // keys[0] quirk of unique_multiscale (see k_zero_chain)
+    HIP_TRY(hipMemsetAsync(p->chain, 0xFF, 4 * sizeof(unsigned long long), p->stream));
+    ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
+    for (int j = 0; j < 3; ++j)
+      hipLaunchKernelGGL(k_min_key, dim3(64), dim3(SE_WG), 0, p->stream, m, p->chain + j, p->chain + (j ? j - 1 : 0), j ? 1 : 0);
+    hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(64), 0, p->stream, m, p->chain);
+  }
+  HIP_TRY(hipGetLastError());
+  return 1;
+}
+
+int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* capacity_words) {
+  if (int r = check(p)) return r;
+  if (device_list) *device_list = (uint64_t*)p->map.newkeys;
+  if (capacity_words) *capacity_words = (int64_t)p->map.cap_keys + 1;
+  return SE_HIP_OK;
+}
+
+int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
+  if (int r = check(p)) return r;
+  if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
+  ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
+  hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, (const unsigned long long*)device_lists, nlists, (long long)stride_words);
+  HIP_TRY(hipGetLastError());
+  return SE_HIP_OK;
+}
+
+int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  if (int r = check(p)) return r;
+  if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!stage_runs_integration(frame, rate)) return 0;
+  const DevMap& m = p->map;
+  const M4 pose = from_colmajor(pose_cm);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  IntegArgs a{};
+  // Sophus::SE3f(pose_).inverse() (DenseSLAMSystem.cpp:237): (R^T, R^T * (t * -1)) taken from the matrix
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a.R[i * 3 + j] = pose.m[j][i];
+  const float nt[3] = {pose.m[0][3] * -1.f, pose.m[1][3] * -1.f, pose.m[2][3] * -1.f};
+  mul3(a.R, nt, a.t);
+  const M4 K = camera_matrix(k);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) a.K3[i * 3 + j] = K.m[i][j];
+  M4 Tcw{};
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Tcw.m[i][j] = a.R[i * 3 + j]; Tcw.m[i][3] = a.t[i]; }
+  Tcw.m[3][0] = Tcw.m[3][1] = Tcw.m[3][2] = 0.f; Tcw.m[3][3] = 1.f;
+  const M4 cam = mul(K, Tcw);                        // projective_functor.hpp:64
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) a.cam[i * 4 + j] = cam.m[i][j];
+  a.voxel = m.dim / (float)m.size;
+  const float vs3[3] = {a.voxel, 0, 0};
+  mul3(a.R, vs3, a.delta);                           // projective_functor.hpp:76-77
+  mul3(a.K3, a.delta, a.cdelta);
+  a.mu = mu;
+  a.maxweight = 100.f;                               // DenseSLAMSystem.cpp:235
+  a.timestamp = (1.f / 30.f) * frame;                // DenseSLAMSystem.cpp:243
+  a.W = p->cfg.width; a.H = p->cfg.height;
+  a.bspline = p->bspline; a.logodds = p->logodds;
+  const dim3 block(SE_WG);
+  {
+    ScopedTimer t(p, SE_HIP_K_INTEGRATE_BLOCKS);
+    const dim3 grid(2048);  // 8192 waves, grid-stride over the allocated blocks (count lives on the device)
+    if (sdf) {
+      if (p->stats) hipLaunchKernelGGL((k_integrate_blocks<false, true>), grid, block, 0, p->stream, m, p->depth, a);
+      else hipLaunchKernelGGL((k_integrate_blocks<false, false>), grid, block, 0, p->stream, m, p->depth, a);
+    } else {
+      if (p->stats) hipLaunchKernelGGL((k_integrate_blocks<true, true>), grid, block, 0, p->stream, m, p->depth, a);
+      else hipLaunchKernelGGL((k_integrate_blocks<true, false>), grid, block, 0, p->stream, m, p->depth, a);
+    }
+  }
+  {
+    ScopedTimer t(p, SE_HIP_K_INTEGRATE_NODES);
+    const dim3 grid(256);
+    if (sdf) hipLaunchKernelGGL(k_integrate_nodes<false>, grid, block, 0, p->stream, m, p->depth, a);
+    else hipLaunchKernelGGL(k_integrate_nodes<true>, grid, block, 0, p->stream, m, p->depth, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return 1;
+}
+
+int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  int r = se_hip_alloc_scan(p, pose, k, rate, mu, frame);
+  if (r <= 0) return r;
+  return se_hip_integrate_sweep(p, pose, k, rate, mu, frame);
+}
+
+// ------------------------------------------------------------------------------------ raycast
+int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4], float mu, uint32_t frame) {
+  if (int r = check(p)) return r;
+  if (!pose_cm || !k) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!(frame > 2)) return 0;  // DenseSLAMSystem.cpp:195
+  const DevMap& m = p->map;
+  const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));  // DenseSLAMSystem.cpp:199
+  RayArgs a{};
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) a.view3[i * 3 + j] = view.m[i][j]; a.org[i] = view.m[i][3]; }
+  a.nearp = 0.4f; a.farp = 4.0f;  // constant_parameters.h:22-32
+  a.mu = mu;
+  a.step = m.dim / (float)m.size;           // DenseSLAMSystem.cpp:197
+  a.largestep = a.step * 8;                 // step * BLOCK_SIDE
+  a.inv_voxel = (float)m.size / m.dim;      // volume_template.hpp:78
+  a.grad_scale = 0.5f * m.dim / (float)m.size;  // octree.hpp:736
+  a.epsilon = exp2f(-(float)p->max_level);  // ray_iterator.hpp:63
+  a.min_scale = 23 - p->leaf_level;         // ray_iterator.hpp:62
+  a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+  const int tiles = ((a.W + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
+  const dim3 grid((tiles + 3) / 4), block(SE_WG);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  {
+    ScopedTimer t(p, SE_HIP_K_RAYCAST);
+    if (sdf) {
+      if (p->stats) hipLaunchKernelGGL((k_raycast<false, true>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
+      else hipLaunchKernelGGL((k_raycast<false, false>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
+    } else {
+      if (p->stats) hipLaunchKernelGGL((k_raycast<true, true>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
+      else hipLaunchKernelGGL((k_raycast<true, false>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 1;
+}
+
+int se_hip_download_vertex_normal(se_hip_pipeline* p, float* v, float* n) {
+  if (int r = check(p)) return r;
+  const size_t bytes = (size_t)p->cfg.width * p->cfg.height * 3 * sizeof(float);
+  if (v) HIP_TRY(hipMemcpyAsync(v, p->vertex, bytes, hipMemcpyDeviceToHost, p->stream));
+  if (n) HIP_TRY(hipMemcpyAsync(n, p->normal, bytes, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return SE_HIP_OK;
+}
+
+int se_hip_vertex_normal_device(se_hip_pipeline* p, float** v, float** n) {
+  if (int r = check(p)) return r;
+  if (v) *v = p->vertex;
+  if (n) *n = p->normal;
+  return SE_HIP_OK;
+}
+
+// ----------------------------------------------------------------------------------- read-back
+static int fetch_counters(se_hip_pipeline* p) {
+  HIP_TRY(hipMemcpyAsync(p->ctr_host, p->map.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->ctr_host[C_OVERFLOW]) return fail(SE_HIP_E_CAPACITY, p->ctr_host[C_OVERFLOW] == 2 ? "new-key list overflow" : "block / node pool exhausted (raise max_blocks)");
+  return SE_HIP_OK;
+}
+
+int se_hip_counts(se_hip_pipeline* p, int32_t* nb, int32_t* nn) {
+  if (int r = check(p)) return r;
+  if (int r = fetch_counters(p)) return r;
+  if (nb) *nb = (int32_t)p->ctr_host[C_BLOCKS];
+  if (nn) *nn = (int32_t)p->ctr_host[C_NODES];
+  return SE_HIP_OK;
+}
+
+int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float* y, uint8_t* active) {
+  if (int r = check(p)) return r;
+  if (int r = fetch_counters(p)) return r;
+  const size_t n = p->ctr_host[C_BLOCKS];
+  if (n == 0) return SE_HIP_OK;
+  std::vector<uint32_t> pos(n);
+  std::vector<uint8_t> act(n);
+  HIP_TRY(hipMemcpy(pos.data(), p->map.bpos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(act.data(), p->map.bactive, n, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> key(n);
+  for (size_t i = 0; i < n; ++i)
+    key[i] = se_make_key(pos[i] & 1023u, (pos[i] >> 10) & 1023u, pos[i] >> 20, p->leaf_level, p->max_level);
+  std::vector<size_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+  std::vector<float> hx, hy;
+  if (x) { hx.resize(n * 512); HIP_TRY(hipMemcpy(hx.data(), p->map.vx, n * 512 * sizeof(float), hipMemcpyDeviceToHost)); }
+  if (y) { hy.resize(n * 512); HIP_TRY(hipMemcpy(hy.data(), p->map.vy, n * 512 * sizeof(float), hipMemcpyDeviceToHost)); }
+  for (size_t i = 0; i < n; ++i) {
+    const size_t s = order[i];
+    if (coords) { coords[3 * i] = (int)(pos[s] & 1023u) << 3; coords[3 * i + 1] = (int)((pos[s] >> 10) & 1023u) << 3; coords[3 * i + 2] = (int)(pos[s] >> 20) << 3; }
+    if (active) active[i] = act[s];
+    if (x) std::memcpy(x + i * 512, hx.data() + s * 512, 512 * sizeof(float));
+    if (y) std::memcpy(y + i * 512, hy.data() + s * 512, 512 * sizeof(float));
+  }
+  return SE_HIP_OK;
+}
+
+int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, float* x, float* y) {
+  if (int r = check(p)) return r;
+  if (int r = fetch_counters(p)) return r;
+  const size_t n = p->ctr_host[C_NODES];
+  std::vector<uint32_t> pos(n);
+  std::vector<uint8_t> lvl(n);
+  std::vector<float> hx(n * 8), hy(n * 8);
+  HIP_TRY(hipMemcpy(pos.data(), p->map.npos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(lvl.data(), p->map.nlevel, n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hx.data(), p->map.nx, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hy.data(), p->map.ny, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> key(n);
+  for (size_t i = 0; i < n; ++i)
+    key[i] = lvl[i] == 0 ? 0ull : se_make_key(pos[i] & 1023u, (pos[i] >> 10) & 1023u, pos[i] >> 20, lvl[i], p->max_level);
+  std::vector<size_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+  for (size_t i = 0; i < n; ++i) {
+    const size_t s = order[i];
+    if (code) code[i] = key[s];
+    if (side) side[i] = (uint32_t)p->map.size >> lvl[s];
+    if (x) std::memcpy(x + i * 8, hx.data() + s * 8, 8 * sizeof(float));
+    if (y) std::memcpy(y + i * 8, hy.data() + s * 8, 8 * sizeof(float));
+  }
+  return SE_HIP_OK;
+}
+
+// --------------------------------------------------------------------------------- measurement
+int se_hip_enable_timing(se_hip_pipeline* p, int32_t on) {
+  if (int r = check(p)) return r;
+  drain_timings(p);
+  p->timing = on != 0;
+  return SE_HIP_OK;
+}
+
+int se_hip_get_timings(se_hip_pipeline* p, double ms_sum[SE_HIP_K_COUNT], int64_t launches[SE_HIP_K_COUNT], int32_t reset) {
+  if (int r = check(p)) return r;
+  drain_timings(p);
+  for (int i = 0; i < SE_HIP_K_COUNT; ++i) {
+    if (ms_sum) ms_sum[i] = p->ms_sum[i];
+    if (launches) launches[i] = p->launches[i];
+    if (reset) { p->ms_sum[i] = 0; p->launches[i] = 0; }
+  }
+  return SE_HIP_OK;
+}
+
+int se_hip_enable_stats(se_hip_pipeline* p, int32_t on) {
+  if (int r = check(p)) return r;
+  p->stats = on != 0;
+  HIP_TRY(hipMemsetAsync(p->map.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream));
+  return SE_HIP_OK;
+}
+
+int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[8], int32_t reset) {
+  if (int r = check(p)) return r;
+  unsigned long long h[S_COUNT];
+  HIP_TRY(hipMemcpyAsync(h, p->map.stats, sizeof h, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (int r = fetch_counters(p)) return r;
+  h[S_NODES] = p->ctr_host[C_NODES];
+  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  if (reset) HIP_TRY(hipMemsetAsync(p->map.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream));
+  return SE_HIP_OK;
+}
+
+}  // extern "C"

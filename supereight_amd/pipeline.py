@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's DenseSLAMSystem hot-path interface over the C ABI.
+
+``DenseSLAMPipeline`` keeps the reference's method names and semantics for the path this
+repository implements (se_denseslam/include/se/DenseSLAMSystem.h:193-212, 295, 353):
+``integration(k, integration_rate, mu, frame)`` and ``raycasting(k, mu, frame)`` return the
+reference's "did this stage run" booleans, ``setPose`` injects the camera pose, ``getMap``-style
+read-back comes from ``blocks()`` / ``nodes()``.  All compute happens in libse_hip.so
+(hand-written HIP for gfx950); there is no CPU fallback -- loading fails loudly without it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SDF, OFUSION = 0, 1
+KERNELS = ("alloc_scan", "alloc_commit", "integrate_blocks", "integrate_nodes", "raycast")
+STAT_NAMES = ("probes", "new_keys", "swept", "nodes", "gets", "interps", "grads", "hits")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_LIB = None
+
+
+class SeHipError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("volume_resolution", C.c_int32),
+                ("volume_dimension", C.c_float), ("field_type", C.c_int32), ("device", C.c_int32),
+                ("max_blocks", C.c_int64), ("row_begin", C.c_int32), ("row_end", C.c_int32)]
+
+
+EXPORTS = {
+    "se_hip_create": (C.c_int, [C.POINTER(_Config), C.POINTER(C.c_void_p)]),
+    "se_hip_destroy": (C.c_int, [C.c_void_p]),
+    "se_hip_last_error": (C.c_char_p, []),
+    "se_hip_sync": (C.c_int, [C.c_void_p]),
+    "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se_hip_upload_depth": (C.c_int, [C.c_void_p, _f32p]),
+    "se_hip_upload_depth_mm": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
+    "se_hip_set_depth_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se_hip_integrate": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_alloc_scan": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_new_keys_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "se_hip_alloc_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
+    "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
+    "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
+    "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "se_hip_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "se_hip_download_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "se_hip_download_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "se_hip_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "se_hip_get_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+    "se_hip_enable_stats": (C.c_int, [C.c_void_p, C.c_int32]),
+    "se_hip_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]),
+}
+
+
+def load_library(rebuild: bool = True):
+    """Load libse_hip.so (building it with hipcc first if it is missing or stale)."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if rebuild:
+            try:
+                path = _build.build()
+            except RuntimeError:
+                if not os.path.exists(path):
+                    raise
+        lib = C.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def _colmajor(m) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(4, 4).T).reshape(16)
+
+
+class DenseSLAMPipeline:
+    def __init__(self, input_size, volume_resolution: int, volume_dimension: float, init_pose=None,
+                 field_type: int = SDF, device: int = 0, max_blocks: int = 0, rows=None):
+        self.lib = load_library()
+        self.W, self.H = int(input_size[0]), int(input_size[1])
+        self.size, self.dim, self.field = int(volume_resolution), float(volume_dimension), field_type
+        rb, re_ = rows if rows is not None else (0, 0)
+        cfg = _Config(self.W, self.H, self.size, self.dim, field_type, device, max_blocks, rb, re_)
+        h = C.c_void_p()
+        self._h = None
+        self._check(self.lib.se_hip_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else np.asarray(init_pose, np.float32).copy()
+        self._keepalive = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, status: int) -> int:
+        if status < 0:
+            raise SeHipError(f"se_hip error {status}: {self.lib.se_hip_last_error().decode()}")
+        return status
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.se_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.se_hip_sync(self._h))
+
+    def set_stream(self, hip_stream_ptr: int):
+        self._check(self.lib.se_hip_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def setPose(self, pose):
+        """DenseSLAMSystem::setPose semantics minus the init-pose offset: pose is camera->world."""
+        self.pose_ = np.asarray(pose, np.float32).reshape(4, 4).copy()
+
+    def getPose(self):
+        return self.pose_.copy()
+
+    def set_depth(self, depth_m):
+        """float_depth_ of the reference: host float32 metres (H, W)."""
+        d = np.ascontiguousarray(depth_m, dtype=np.float32).reshape(-1)
+        assert d.size == self.W * self.H
+        self._check(self.lib.se_hip_upload_depth(self._h, d))
+
+    def set_depth_mm(self, depth_mm):
+        """preprocessing()'s mm2metersKernel fused into the upload: uint16 millimetres (h, w)."""
+        d = np.ascontiguousarray(depth_mm, dtype=np.uint16)
+        self._check(self.lib.se_hip_upload_depth_mm(self._h, d.reshape(-1), d.shape[1], d.shape[0]))
+
+    def set_depth_device(self, ptr: int, keepalive=None):
+        """Zero-copy: a float32 depth image already in HBM (e.g. a torch tensor's data_ptr())."""
+        self._keepalive = keepalive
+        self._check(self.lib.se_hip_set_depth_device(self._h, C.c_void_p(ptr)))
+
+    def integration(self, k, integration_rate: int, mu: float, frame: int) -> bool:
+        return bool(self._check(self.lib.se_hip_integrate(self._h, _colmajor(self.pose_), np.asarray(k, np.float32),
+                                                          integration_rate, mu, frame)))
+
+    def raycasting(self, k, mu: float, frame: int) -> bool:
+        return bool(self._check(self.lib.se_hip_raycast(self._h, _colmajor(self.pose_), np.asarray(k, np.float32), mu, frame)))
+
+    # stage split used by the multi-GPU driver
+    def alloc_scan(self, k, integration_rate: int, mu: float, frame: int) -> bool:
+        return bool(self._check(self.lib.se_hip_alloc_scan(self._h, _colmajor(self.pose_), np.asarray(k, np.float32),
+                                                           integration_rate, mu, frame)))
+
+    def new_keys_device(self):
+        ptr, cap = C.c_void_p(), C.c_int64()
+        self._check(self.lib.se_hip_new_keys_device(self._h, C.byref(ptr), C.byref(cap)))
+        return ptr.value, cap.value
+
+    def alloc_commit(self, lists_ptr: int, nlists: int, stride_words: int):
+        self._check(self.lib.se_hip_alloc_commit(self._h, C.c_void_p(lists_ptr), nlists, stride_words))
+
+    def integrate_sweep(self, k, integration_rate: int, mu: float, frame: int) -> bool:
+        return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, _colmajor(self.pose_), np.asarray(k, np.float32),
+                                                                integration_rate, mu, frame)))
+
+    # ------------------------------------------------------------------ outputs
+    def vertex_normal(self):
+        v = np.zeros((self.H, self.W, 3), np.float32)
+        n = np.zeros((self.H, self.W, 3), np.float32)
+        self._check(self.lib.se_hip_download_vertex_normal(self._h, v.reshape(-1), n.reshape(-1)))
+        return v, n
+
+    def vertex_normal_device(self):
+        v, n = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.se_hip_vertex_normal_device(self._h, C.byref(v), C.byref(n)))
+        return v.value, n.value
+
+    def counts(self):
+        nb, nn = C.c_int32(), C.c_int32()
+        self._check(self.lib.se_hip_counts(self._h, C.byref(nb), C.byref(nn)))
+        return nb.value, nn.value
+
+    def blocks(self):
+        nb, _ = self.counts()
+        coords = np.zeros((nb, 3), np.int32)
+        x = np.zeros((nb, 512), np.float32)
+        y = np.zeros((nb, 512), np.float32)
+        act = np.zeros(nb, np.uint8)
+        if nb:
+            self._check(self.lib.se_hip_download_blocks(self._h, coords.ctypes.data, x.ctypes.data, y.ctypes.data, act.ctypes.data))
+        return coords, x, y, act
+
+    def nodes(self):
+        _, nn = self.counts()
+        code = np.zeros(nn, np.uint64)
+        side = np.zeros(nn, np.uint32)
+        x = np.zeros((nn, 8), np.float32)
+        y = np.zeros((nn, 8), np.float32)
+        self._check(self.lib.se_hip_download_nodes(self._h, code.ctypes.data, side.ctypes.data, x.ctypes.data, y.ctypes.data))
+        return code, side, x, y
+
+    # ------------------------------------------------------------------ measurement
+    def enable_timing(self, on: bool = True):
+        self._check(self.lib.se_hip_enable_timing(self._h, int(on)))
+
+    def timings(self, reset: bool = False) -> dict:
+        ms = (C.c_double * len(KERNELS))()
+        n = (C.c_int64 * len(KERNELS))()
+        self._check(self.lib.se_hip_get_timings(self._h, ms, n, int(reset)))
+        return {k: {"ms_sum": ms[i], "launches": n[i]} for i, k in enumerate(KERNELS)}
+
+    def enable_stats(self, on: bool = True):
+        self._check(self.lib.se_hip_enable_stats(self._h, int(on)))
+
+    def stats(self, reset: bool = False) -> dict:
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.se_hip_get_stats(self._h, out, int(reset)))
+        return dict(zip(STAT_NAMES, (int(v) for v in out)))

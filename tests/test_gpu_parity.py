@@ -1,0 +1,90 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded
+synthetic frames.  Bit-exactness is the gate for map state (integer block / node sets, float
+TSDF / weight / log-odds values): both sides evaluate IEEE binary32 in the same order with FMA
+contraction off.  Raycast output is gated the same way; the looser SURVEY 8(d) tolerances are
+printed for information.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from oracle.binding import OFUSION, SDF
+from tests.parity_util import compare_maps, compare_raycast, run_both
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, field, W, H, N, dim, mu, frames
+    ("sdf_160x120_256", SDF, 160, 120, 256, 2.4, 0.1, 6),
+    ("sdf_640x480_512", SDF, 640, 480, 512, 4.8, 0.1, 6),       # BASELINE.json configs[1]
+    ("sdf_320x240_1024", SDF, 320, 240, 1024, 4.8, 0.1, 5),     # configs[2] geometry, smaller image
+    ("ofusion_160x120_256", OFUSION, 160, 120, 256, 2.4, 0.02, 6),
+    ("ofusion_640x480_512", OFUSION, 640, 480, 512, 4.8, 0.008, 5),   # configs[4], the reference's own ofusion mu (Makefile:39)
+]
+
+
+@pytest.mark.parametrize("name,field,W,H,N,dim,mu,frames", CASES, ids=[c[0] for c in CASES])
+def test_stream_parity(name, field, W, H, N, dim, mu, frames):
+    cpu, gpu, recs = run_both(field, W, H, N, dim, mu, frames)
+    m = compare_maps(cpu, gpu)
+    print(name, "map:", json.dumps(m))
+    assert cpu.stats()["oob"] == 0          # no sample left the volume -> reference behaviour is defined
+    assert m["same_block_set"], m
+    assert m["same_node_set"], m
+    assert m["x_mismatch"] == 0 and m["y_mismatch"] == 0, m
+    assert m["active_mismatch"] == 0, m
+    assert m["node_x_mismatch"] == 0 and m["node_y_mismatch"] == 0, m
+    voxel = dim / N
+    for rec in recs:
+        if not rec["raycast"]:
+            continue
+        r = compare_raycast(rec, voxel)
+        print(name, "frame", rec["frame"], "raycast:", json.dumps(r))
+        assert r["hitmask_mismatch"] == 0, r
+        assert r["vertex_bit_mismatch_px"] == 0, r
+        assert r["normal_bit_mismatch_px"] == 0, r
+    cpu.close()
+    gpu.close()
+
+
+def test_gating_and_empty_input():
+    """frame gates of DenseSLAMSystem.cpp:195,209 and an all-zero depth image (nothing allocated)."""
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    from supereight_amd.synthetic import intrinsics, pose
+    p = DenseSLAMPipeline((64, 48), 128, 1.2)
+    p.set_depth(np.zeros((48, 64), np.float32))
+    p.setPose(pose(0, 1.2))
+    k = intrinsics(64)
+    assert p.integration(k, 2, 0.1, 0) is True       # frame <= 3 always integrates
+    assert p.integration(k, 2, 0.1, 5) is False      # 5 % 2 != 0
+    assert p.integration(k, 2, 0.1, 6) is True
+    assert p.raycasting(k, 0.1, 2) is False and p.raycasting(k, 0.1, 3) is True
+    assert p.counts() == (0, 1)                       # only the root node
+    v, n = p.vertex_normal()
+    assert (v == 0).all() and (n[..., 0] == -2).all() and (n[..., 1:] == 0).all()
+    p.close()
+
+
+def test_mm2meters_fused_upload():
+    """se_hip_upload_depth_mm == mm2metersKernel (preprocessing.cpp:161-188) incl. subsampling."""
+    from supereight_amd.pipeline import DenseSLAMPipeline, SeHipError
+    from supereight_amd.synthetic import intrinsics, pose, render_depth_mm
+    W, H, N, dim = 80, 60, 128, 2.4
+    mm = render_depth_mm(0, 2 * W, 2 * H, dim)
+    ref = (mm[::2, ::2].astype(np.float32) / np.float32(1000.0))
+    a = DenseSLAMPipeline((W, H), N, dim)
+    b = DenseSLAMPipeline((W, H), N, dim)
+    a.set_depth_mm(mm)
+    b.set_depth(ref)
+    k = intrinsics(W)
+    for q in (a, b):
+        q.setPose(pose(0, dim))
+        q.integration(k, 1, 0.1, 0)
+    ca, xa, ya, _ = a.blocks()
+    cb, xb, yb, _ = b.blocks()
+    assert len(ca) > 0 and (ca == cb).all() and (xa == xb).all() and (ya == yb).all()
+    with pytest.raises(SeHipError):
+        a.set_depth_mm(np.zeros((H + 1, W), np.uint16))   # "Invalid ratio."
+    a.close()
+    b.close()
