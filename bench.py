@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec of integration() + raycasting() on the synthetic 640x480 depth
+stream into a 512^3 / 4.8 m TSDF (BASELINE.json metric; configs[1] at N=1).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame of the hot path: allocation scan + integration sweep + raycast.  The depth
+frames are generated before the timed region and are resident in HBM; poses are 64-byte kernel
+arguments.  N > 1 shards the image rows of ONE stream across ranks with one RCCL all-gather of the
+new-block key lists per frame (supereight_amd/multi_gpu.py): total work is fixed -> "strong".
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     for the dominant kernel (largest share of GPU time): algorithmic bytes per launch
+               (SURVEY.md 8(d) formulas, work counts taken from an instrumented replay of the same
+               frames) / average launch duration from HIP events recorded on the launch stream
+               during the timed region; peak = 8 TB/s HBM3E.
+  cpu_baseline the CPU oracle (reference-equivalent OpenMP restatement, kind "port") timed on this
+               host's cores on a bounded sample of the same stream (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak ~6300 GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--dim", type=float, default=4.8)
+    ap.add_argument("--mu", type=float, default=0.1)
+    ap.add_argument("--field", choices=["sdf", "ofusion"], default="sdf")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--event-stride", type=int, default=10,
+                    help="record per-kernel HIP events on every n-th timed frame (1 = every frame; events cost host time)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=30, help="timed frames of the CPU baseline sample")
+    ap.add_argument("--detail", type=str, default="", help="write a detailed JSON report to this path")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(stats: dict, frames: int, W: int, H: int, voxel_bytes: int) -> dict:
+    """per-launch algorithmic bytes of each kernel (every kernel is launched once per
+    frame), from work counts summed over the timed frames.  voxel_bytes = sizeof(voxel) of the
+    reference layout (8 SDF, 16 OFusion)."""
+    n = max(1, frames)
+    # A_int = N_swept*512*sizeof(voxel)*2 + W*H*4 + N_nodes*8*sizeof(voxel)*2 (every node is swept every frame)
+    a_int = stats["swept"] / n * 512 * voxel_bytes * 2 + W * H * 4 + stats["nodes"] * 8 * voxel_bytes * 2
+    a_alloc = W * H * 4 + stats["probes"] / n * 4
+    a_ray = W * H * 24 + (stats["gets"] + 8 * stats["interps"] + 32 * stats["grads"]) / n * voxel_bytes
+    return {"integrate": a_int, "alloc_scan": a_alloc, "raycast": a_ray}
+
+
+def cpu_baseline(args, n_timed: int):
+    """Times the CPU oracle on frames 0..3 (warm-up, executed but excluded as in SURVEY 8(d)) plus
+    n_timed frames of the same stream; fps = n / sum(t_integration + t_raycasting)."""
+    from oracle import binding
+    from supereight_amd.synthetic import SyntheticStream
+    try:
+        binding.load(native=True)
+        native = True
+    except Exception:
+        native = False
+    field = binding.SDF if args.field == "sdf" else binding.OFUSION
+    o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
+    threads = o.lib.so_num_threads()
+    s = SyntheticStream(args.width, args.height, args.dim)
+    t_sum, t_int_sum, t_ray_sum = 0.0, 0.0, 0.0
+    for f in range(4 + n_timed):
+        d, pose = s.depth(f), s.pose(f)
+        t0 = time.perf_counter()
+        o.integrate(d, pose, s.k, args.mu, f)
+        t1 = time.perf_counter()
+        o.raycast(pose, s.k, args.mu, f)
+        t2 = time.perf_counter()
+        if f >= 4:
+            t_int_sum += t1 - t0
+            t_ray_sum += t2 - t1
+    t_sum = t_int_sum + t_ray_sum
+    o.close()
+    return {"value": n_timed / t_sum, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"frames 4..{3 + n_timed} of the same synthetic stream after 4 executed warm-up frames "
+                      f"({n_timed} timed frames, OpenMP {threads} threads, {'-march=native' if native else '-march=x86-64-v3'} build)",
+            "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed}
+
+
+def main():
+    args = parse()
+    # OpenMP placement for the CPU baseline leg must be set before libgomp is loaded
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    import torch
+    import torch.distributed as dist
+    from supereight_amd.multi_gpu import ShardedPipeline, row_partition
+    from supereight_amd.pipeline import OFUSION, SDF, DenseSLAMPipeline
+    from supereight_amd.synthetic import SyntheticStream
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    field = SDF if args.field == "sdf" else OFUSION
+    W, H, N, dim, mu = args.width, args.height, args.res, args.dim, args.mu
+    warm = max(args.warmup, 4)   # frames 0..3 are the reference's own warm-up (forced integration, no raycast before frame 3)
+    K = args.steps
+    F = warm + K
+
+    # ---- inputs: the whole stream resident in HBM before anything is timed
+    stream = SyntheticStream(W, H, dim)
+    host_depth = np.stack([stream.depth(f) for f in range(F)])
+    poses = [stream.pose(f) for f in range(F)]
+    k = stream.k
+    dev = torch.device("cuda", local_rank)
+    depth = torch.from_numpy(host_depth).to(dev)
+    depth_ptrs = [depth[f].data_ptr() for f in range(F)]
+
+    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for f in range(warm):
+        sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+    torch.cuda.synchronize()
+    sp.p.counts()  # raises if a pool or key list overflowed during warm-up
+    stride = max(1, args.event_stride)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(warm, F):
+        if not args.no_events:
+            sp.p.enable_timing((f - warm) % stride == 0)   # sampled: HIP events on the launch stream
+        sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timings = sp.p.timings(reset=True) if not args.no_events else None
+    sp.p.enable_timing(False)
+    nblocks, nnodes = sp.p.counts()
+    sp.close()
+
+    result = None
+    if rank == 0:
+        fps = K / elapsed
+        result = {
+            "metric": "frames/sec (integrate+raycast), 640x480 depth -> 512^3 TSDF",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": warm,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic room+sphere depth stream {W}x{H} -> {N}^3 / {dim} m "
+                                   f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
+                                   f"GT poses, frames {warm}..{F - 1} timed",
+                       "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists",
+                       "blocks_allocated": nblocks, "nodes_allocated": nnodes},
+        }
+
+    # ---- roofline of the dominant kernel (rank 0, its own share of the image)
+    if rank == 0 and timings is not None and world > 1:
+        result["kernels"] = {kk: {"avg_us": 1e3 * v["ms_sum"] / v["launches"], "launches": v["launches"]}
+                             for kk, v in timings.items() if v["launches"]}
+    if rank == 0 and timings is not None and world == 1:
+        rows = (0, H)
+        rp = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=local_rank)
+        rp.enable_stats(True)
+        # instrumented replay of the same frames: exact work counts of the timed launches
+        for f in range(F):
+            rp.set_depth_device(depth_ptrs[f])
+            rp.setPose(poses[f])
+            if f == warm:
+                rp.stats(reset=True)
+            rp.integration(k, 1, mu, f)
+            rp.raycasting(k, mu, f)
+        st = rp.stats()
+        rp.close()
+        abytes = algorithmic_bytes(st, K, W, H, 8 if field == SDF else 16)
+        per_kernel = {}
+        for kk, v in timings.items():
+            if v["launches"] == 0:
+                continue
+            avg_ms = v["ms_sum"] / v["launches"]
+            per_kernel[kk] = {"avg_us": 1e3 * avg_ms, "launches": v["launches"], "share": v["ms_sum"]}
+            if kk in abytes:
+                per_kernel[kk]["algorithmic_bytes"] = abytes[kk]
+                per_kernel[kk]["GBps"] = abytes[kk] / (avg_ms * 1e-3) / 1e9
+        tot = sum(v["share"] for v in per_kernel.values())
+        for v in per_kernel.values():
+            v["share"] = v["share"] / tot if tot else 0.0
+        dom = max((kk for kk in per_kernel if "GBps" in per_kernel[kk]), key=lambda kk: per_kernel[kk]["share"])
+        result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                              "avg_launch_us": per_kernel[dom]["avg_us"],
+                              "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes"]}
+        result["kernels"] = per_kernel
+        result["work_per_frame"] = {kk: st[kk] / K for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
+
+    del depth
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, args.cpu_frames)
+        result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if rank == 0:
+        if args.detail:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, "w") as fh:
+                json.dump(result, fh, indent=1)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

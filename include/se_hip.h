@@ -93,6 +93,9 @@ int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4],
 int se_hip_alloc_scan(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate, float mu,
                       uint32_t frame);
 int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* capacity_words);
+/* Make the scan write its list into caller-owned device memory (e.g. the send buffer of the RCCL
+ * allgather); capacity_words includes the count word.  NULL restores the internal buffer. */
+int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_t capacity_words);
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words);
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate,
                            float mu, uint32_t frame);
@@ -116,10 +119,9 @@ int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, fl
 /* ---- measurement (replaces TICK()/TOCK() + PerfStats, se_shared/timings.h:7-15) */
 #define SE_HIP_K_ALLOC_SCAN 0
 #define SE_HIP_K_ALLOC_COMMIT 1
-#define SE_HIP_K_INTEGRATE_BLOCKS 2
-#define SE_HIP_K_INTEGRATE_NODES 3
-#define SE_HIP_K_RAYCAST 4
-#define SE_HIP_K_COUNT 5
+#define SE_HIP_K_INTEGRATE 2 /* block sweep + node sweep, one launch */
+#define SE_HIP_K_RAYCAST 3
+#define SE_HIP_K_COUNT 4
 /* HIP-event timing of every kernel launch on the handle's stream (off by default). */
 int se_hip_enable_timing(se_hip_pipeline* p, int32_t on);
 /* sum of launch durations [ms] and number of launches per kernel since the last reset */

@@ -75,6 +75,8 @@ struct se_hip_pipeline {
   float* bspline = nullptr;
   float* logodds = nullptr;
   unsigned long long* chain = nullptr;  // 3 candidates for the keys[0] quirk
+  unsigned long long* newkeys_own = nullptr;
+  unsigned long long cap_keys_own = 0;
   uint32_t* ctr_host = nullptr;         // pinned
   bool timing = false, stats = false;
   std::vector<TimedLaunch> pending;
@@ -82,6 +84,7 @@ struct se_hip_pipeline {
   double ms_sum[SE_HIP_K_COUNT] = {0};
   int64_t launches[SE_HIP_K_COUNT] = {0};
   int row_begin = 0, row_end = 0;
+  int integ_grid = 2048;  // workgroups of the integration sweep (4 waves each)
 };
 
 namespace {
@@ -222,6 +225,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(m.ctr, C_COUNT * sizeof(uint32_t));
   ALLOC(m.stats, S_COUNT * sizeof(unsigned long long));
   ALLOC(m.newkeys, (m.cap_keys + 1) * sizeof(unsigned long long));
+  p->newkeys_own = m.newkeys; p->cap_keys_own = m.cap_keys;
   ALLOC(p->depth_own, (size_t)cfg->width * cfg->height * sizeof(float));
   ALLOC(p->vertex, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   ALLOC(p->normal, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
@@ -270,7 +274,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, m.newkeys,
+  void* ptrs[] = {m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain};
   for (void* q : ptrs) if (q) hipFree(q);
   if (p->ctr_host) hipHostFree(p->ctr_host);
@@ -383,6 +387,14 @@ int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* 
   return SE_HIP_OK;
 }
 
+int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_t capacity_words) {
+  if (int r = check(p)) return r;
+  if (device_list && capacity_words < 2) return fail(SE_HIP_E_INVALID, "key buffer too small");
+  p->map.newkeys = device_list ? (unsigned long long*)device_list : p->newkeys_own;
+  p->map.cap_keys = device_list ? (unsigned long long)(capacity_words - 1) : p->cap_keys_own;
+  return SE_HIP_OK;
+}
+
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
@@ -425,21 +437,16 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   a.bspline = p->bspline; a.logodds = p->logodds;
   const dim3 block(SE_WG);
   {
-    ScopedTimer t(p, SE_HIP_K_INTEGRATE_BLOCKS);
-    const dim3 grid(2048);  // 8192 waves, grid-stride over the allocated blocks (count lives on the device)
+    // one launch: blocks (one wave each, grid-stride; the block count lives on the device) then nodes
+    ScopedTimer t(p, SE_HIP_K_INTEGRATE);
+    const dim3 grid(p->integ_grid);
     if (sdf) {
-      if (p->stats) hipLaunchKernelGGL((k_integrate_blocks<false, true>), grid, block, 0, p->stream, m, p->depth, a);
-      else hipLaunchKernelGGL((k_integrate_blocks<false, false>), grid, block, 0, p->stream, m, p->depth, a);
+      if (p->stats) hipLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, p->stream, m, p->depth, a);
+      else hipLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, p->stream, m, p->depth, a);
     } else {
-      if (p->stats) hipLaunchKernelGGL((k_integrate_blocks<true, true>), grid, block, 0, p->stream, m, p->depth, a);
-      else hipLaunchKernelGGL((k_integrate_blocks<true, false>), grid, block, 0, p->stream, m, p->depth, a);
+      if (p->stats) hipLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, p->stream, m, p->depth, a);
+      else hipLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, p->stream, m, p->depth, a);
     }
-  }
-  {
-    ScopedTimer t(p, SE_HIP_K_INTEGRATE_NODES);
-    const dim3 grid(256);
-    if (sdf) hipLaunchKernelGGL(k_integrate_nodes<false>, grid, block, 0, p->stream, m, p->depth, a);
-    else hipLaunchKernelGGL(k_integrate_nodes<true>, grid, block, 0, p->stream, m, p->depth, a);
   }
   HIP_TRY(hipGetLastError());
   return 1;
@@ -576,8 +583,7 @@ int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, fl
 // --------------------------------------------------------------------------------- measurement
 int se_hip_enable_timing(se_hip_pipeline* p, int32_t on) {
   if (int r = check(p)) return r;
-  drain_timings(p);
-  p->timing = on != 0;
+  p->timing = on != 0;  // no synchronisation here: pending events are resolved by se_hip_get_timings
   return SE_HIP_OK;
 }
 

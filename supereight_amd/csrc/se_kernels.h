@@ -312,15 +312,53 @@ __device__ __forceinline__ bool se_in_frustum(const IntegArgs& a, int bx8, int b
   return px >= 0 && px < a.W && py >= 0 && py < a.H;
 }
 
-// One wave per block, lane = x + 8*y, loop over z: every z-slice is one coalesced 256-byte row of
-// each SoA plane.  build_active_list's predicate (active || in_frustum) is evaluated per block at
-// the top (wave-uniform), update_block's visibility flag is a wave ballot.
+// update_node (projective_functor.hpp:113-137): one thread per (node, child corner).
+// unpack_morton(node->code_) is applied to the full key in the reference, so the level bits
+// leak into the corner position: bit0 -> x+1, bit1 -> y+1, bit2 -> z+1, bit3 -> x+2.
+template <bool OFUSION>
+__device__ __forceinline__ void se_update_node_corner(const DevMap& m, const float* __restrict__ depthmap, const IntegArgs& a, uint32_t tid) {
+  const uint32_t n = tid >> 3;
+  const int i = tid & 7;
+  const int level = m.nlevel[n];
+  const uint32_t np = m.npos[n];
+  const int sh = m.max_level - level;
+  const unsigned side = (unsigned)m.size >> level;
+  const int vx0 = ((int)(np & 1023u) << sh) + (level & 1) + (((level >> 3) & 1) << 1);
+  const int vy0 = ((int)((np >> 10) & 1023u) << sh) + ((level >> 1) & 1);
+  const int vz0 = ((int)(np >> 20) << sh) + ((level >> 2) & 1);
+  const float s = 0.5f * a.voxel * side;
+  const f3 delta = m3_mul(a.R, {s, s, s});
+  const f3 delta_c = m3_mul(a.K3, delta);
+  const f3 base_cam = f3_add(m3_mul(a.R, f3_scale(a.voxel, {(float)vx0, (float)vy0, (float)vz0})), {a.t[0], a.t[1], a.t[2]});
+  const f3 basepix_hom = m3_mul(a.K3, base_cam);
+  const f3 dir = {(float)((i & 1) > 0), (float)((i & 2) > 0), (float)((i & 4) > 0)};
+  const f3 vox_cam = f3_add(base_cam, f3_mul(dir, delta));
+  const f3 pix_hom = f3_add(basepix_hom, f3_mul(dir, delta_c));
+  if (vox_cam.z < 0.0001f) return;
+  const float inverse_depth = 1.f / pix_hom.z;
+  const float pixx = pix_hom.x * inverse_depth + 0.5f;
+  const float pixy = pix_hom.y * inverse_depth + 0.5f;
+  if (pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f) return;
+  float vx = m.nx[tid], vy = m.ny[tid];
+  bool dirty = false;
+  if (OFUSION) se_bfusion_update(a, depthmap, vox_cam, pixx, pixy, vx, vy, dirty);
+  else se_sdf_update(a, depthmap, vox_cam, pixx, pixy, vx, vy, dirty);
+  if (dirty) { m.nx[tid] = vx; m.ny[tid] = vy; }
+}
+
+// projective_functor::apply (projective_functor.hpp:139-160) in one launch.
+// Blocks: one wave per block, lane = x + 8*y, all 8 z-slices in flight: every slice is one
+// coalesced 256-byte row of each SoA plane and the 16 loads of a lane are issued before the first
+// use.  build_active_list's predicate (active || in_frustum) is evaluated per block at the top
+// (wave-uniform), update_block's visibility flag is a wave ballot.  Internal nodes (8 corner
+// values each) are swept by the same grid afterwards, one thread per corner.
 template <bool OFUSION, bool STATS>
-__global__ __launch_bounds__(SE_WG) void k_integrate_blocks(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
+__global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * SE_WG + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * SE_WG) >> 6;
   const uint32_t nblocks = min(m.ctr[C_BLOCKS], m.cap_blocks);
+  const uint32_t nnodes = min(m.ctr[C_NODES], m.cap_nodes);
   const int lx = lane & 7, ly = lane >> 3;
   unsigned long long swept = 0;
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
@@ -328,17 +366,20 @@ __global__ __launch_bounds__(SE_WG) void k_integrate_blocks(DevMap m, const floa
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
     if (!m.bactive[b] && !se_in_frustum(a, bx, by, bz)) continue;
     if (STATS && lane == 0) ++swept;
-    bool visible = false;
     float* px = m.vx + (size_t)b * 512 + lane;
     float* py = m.vy + (size_t)b * 512 + lane;
+    float vx[8], vy[8];
+#pragma unroll
+    for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
+    bool visible = false;
     const int y = by + ly;
-#pragma unroll 2
+    const float fx = (float)lx;
+#pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
       const int z = bz + zi;
       // update_block: projective_functor.hpp:73-111
       const f3 start = f3_add(m3_mul(a.R, {bx * a.voxel, y * a.voxel, z * a.voxel}), {a.t[0], a.t[1], a.t[2]});
       const f3 camerastart = m3_mul(a.K3, start);
-      const float fx = (float)lx;
       const f3 camera_voxel = f3_add(camerastart, f3_scale(fx, {a.cdelta[0], a.cdelta[1], a.cdelta[2]}));
       const f3 pos = f3_add(start, f3_scale(fx, {a.delta[0], a.delta[1], a.delta[2]}));
       if (pos.z < 0.0001f) continue;
@@ -347,53 +388,17 @@ __global__ __launch_bounds__(SE_WG) void k_integrate_blocks(DevMap m, const floa
       const float pixy = camera_voxel.y * inverse_depth + 0.5f;
       if (pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f) continue;
       visible = true;
-      float vx = px[zi * 64], vy = py[zi * 64];
       bool dirty = false;
-      if (OFUSION) se_bfusion_update(a, depthmap, pos, pixx, pixy, vx, vy, dirty);
-      else se_sdf_update(a, depthmap, pos, pixx, pixy, vx, vy, dirty);
-      if (dirty) { px[zi * 64] = vx; py[zi * 64] = vy; }
+      if (OFUSION) se_bfusion_update(a, depthmap, pos, pixx, pixy, vx[zi], vy[zi], dirty);
+      else se_sdf_update(a, depthmap, pos, pixx, pixy, vx[zi], vy[zi], dirty);
+      if (dirty) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[b] = any ? 1 : 0;  // block->active(is_visible)
   }
   if (STATS && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
-}
-
-// update_node (projective_functor.hpp:113-137): one thread per (node, child corner).
-// unpack_morton(node->code_) is applied to the full key in the reference, so the level bits
-// leak into the corner position: bit0 -> x+1, bit1 -> y+1, bit2 -> z+1, bit3 -> x+2.
-template <bool OFUSION>
-__global__ __launch_bounds__(SE_WG) void k_integrate_nodes(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
-  const uint32_t nnodes = min(m.ctr[C_NODES], m.cap_nodes);
-  for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG) {
-    const uint32_t n = tid >> 3;
-    const int i = tid & 7;
-    const int level = m.nlevel[n];
-    const uint32_t np = m.npos[n];
-    const int sh = m.max_level - level;
-    const unsigned side = (unsigned)m.size >> level;
-    const int vx0 = ((int)(np & 1023u) << sh) + (level & 1) + (((level >> 3) & 1) << 1);
-    const int vy0 = ((int)((np >> 10) & 1023u) << sh) + ((level >> 1) & 1);
-    const int vz0 = ((int)(np >> 20) << sh) + ((level >> 2) & 1);
-    const float s = 0.5f * a.voxel * side;
-    const f3 delta = m3_mul(a.R, {s, s, s});
-    const f3 delta_c = m3_mul(a.K3, delta);
-    const f3 base_cam = f3_add(m3_mul(a.R, f3_scale(a.voxel, {(float)vx0, (float)vy0, (float)vz0})), {a.t[0], a.t[1], a.t[2]});
-    const f3 basepix_hom = m3_mul(a.K3, base_cam);
-    const f3 dir = {(float)((i & 1) > 0), (float)((i & 2) > 0), (float)((i & 4) > 0)};
-    const f3 vox_cam = f3_add(base_cam, f3_mul(dir, delta));
-    const f3 pix_hom = f3_add(basepix_hom, f3_mul(dir, delta_c));
-    if (vox_cam.z < 0.0001f) continue;
-    const float inverse_depth = 1.f / pix_hom.z;
-    const float pixx = pix_hom.x * inverse_depth + 0.5f;
-    const float pixy = pix_hom.y * inverse_depth + 0.5f;
-    if (pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f) continue;
-    float vx = m.nx[tid], vy = m.ny[tid];
-    bool dirty = false;
-    if (OFUSION) se_bfusion_update(a, depthmap, vox_cam, pixx, pixy, vx, vy, dirty);
-    else se_sdf_update(a, depthmap, vox_cam, pixx, pixy, vx, vy, dirty);
-    if (dirty) { m.nx[tid] = vx; m.ny[tid] = vy; }
-  }
+  for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG)
+    se_update_node_corner<OFUSION>(m, depthmap, a, tid);
 }
 
 // ------------------------------------------------------------------------------------------

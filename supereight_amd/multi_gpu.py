@@ -1,0 +1,103 @@
+"""Multi-GPU driver of the dense-fusion path: one process per GPU, image rows sharded across ranks,
+one RCCL all-gather of the per-rank new-block key lists per frame (BASELINE.json north_star,
+SURVEY.md section 8e).
+
+Per frame and rank r of R:
+  1. allocation scan over the rank's image rows -> blocks allocated locally + a key list
+     ``[count, key_1, ...]`` written straight into the all-gather send buffer;
+  2. ``all_gather_into_tensor`` of the fixed-capacity lists (count in word 0, so no separate size
+     exchange; over xGMI every peer is one hop away and the message is latency-bound);
+  3. every rank inserts the other ranks' keys -> all replicas hold the same block set;
+  4. integration sweep (replicated: every replica must hold every voxel update because later
+     frames raycast the map from other view points);
+  5. raycast of the rank's image rows.
+
+The map is replicated, the image-space work (1, 5) is sharded.  ``torch.distributed`` is only the
+transport (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests of the exchange logic).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+# frames <= 3 always integrate (DenseSLAMSystem.cpp:209) and build the map from nothing: their
+# key lists are large.  Later frames only add what newly came into view.
+BIG_FRAMES = 3
+
+
+def row_partition(height: int, world: int, align: int = 8) -> List[Tuple[int, int]]:
+    """Contiguous row tiles, boundaries aligned to the 8-row raycast tile, covering [0, height)."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    units = (height + align - 1) // align
+    bounds = [min(height, align * ((units * r) // world)) for r in range(world)] + [height]
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def exchange_key_lists(local, world: int, group=None):
+    """All-gather fixed-capacity key lists.  ``local`` is a 1-D int64 tensor ``[count, keys...]``;
+    returns a ``world * len(local)`` tensor holding every rank's list in rank order."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    if world == 1:
+        out.copy_(local)
+    else:
+        dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def merged_keys(gathered, world: int) -> np.ndarray:
+    """Host-side view of an exchanged buffer: the concatenation of all valid keys (uint64)."""
+    g = gathered.detach().cpu().numpy().view(np.uint64).reshape(world, -1)
+    parts = []
+    for r in range(world):
+        n = int(g[r, 0])
+        if n > g.shape[1] - 1:
+            raise OverflowError(f"rank {r} produced {n} keys, exchange capacity is {g.shape[1] - 1}")
+        parts.append(g[r, 1:1 + n])
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+
+
+class ShardedPipeline:
+    """Row-sharded DenseSLAMPipeline replica of one rank."""
+
+    def __init__(self, input_size, volume_resolution, volume_dimension, field_type, rank, world, device,
+                 small_words: int = 1 << 16, big_words: int = 0, max_blocks: int = 0, group=None):
+        import torch
+        from .pipeline import DenseSLAMPipeline
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        rows = row_partition(int(input_size[1]), world)[rank]
+        self.rows = rows
+        self.p = DenseSLAMPipeline(input_size, volume_resolution, volume_dimension, field_type=field_type,
+                                   device=device, max_blocks=max_blocks, rows=rows)
+        dev = torch.device("cuda", device)
+        _, cap = self.p.new_keys_device()
+        self.big_words = int(big_words) if big_words else int(min(cap, 1 << 22))
+        self.small_words = int(min(small_words, self.big_words))
+        self.send = torch.zeros(self.big_words, dtype=torch.int64, device=dev)
+        self.recv = torch.zeros(world * self.big_words, dtype=torch.int64, device=dev)
+        # every launch of the replica and the collective share torch's current stream
+        self.p.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def frame(self, depth_ptr: int, pose, k, mu: float, frame: int, integration_rate: int = 1):
+        p = self.p
+        p.set_depth_device(depth_ptr)
+        p.setPose(pose)
+        words = self.big_words if frame <= BIG_FRAMES else self.small_words
+        p.set_new_keys_buffer(self.send.data_ptr(), words, keepalive=self.send)
+        ran = p.alloc_scan(k, integration_rate, mu, frame)
+        if ran:
+            if self.world > 1:
+                import torch.distributed as dist
+                recv = self.recv[: self.world * words]
+                dist.all_gather_into_tensor(recv, self.send[:words], group=self.group)
+                p.alloc_commit(recv.data_ptr(), self.world, words)
+            p.integrate_sweep(k, integration_rate, mu, frame)
+        p.raycasting(k, mu, frame)
+        return ran
+
+    def close(self):
+        self.p.close()

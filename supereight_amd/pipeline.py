@@ -17,7 +17,7 @@ import numpy as np
 from . import build as _build
 
 SDF, OFUSION = 0, 1
-KERNELS = ("alloc_scan", "alloc_commit", "integrate_blocks", "integrate_nodes", "raycast")
+KERNELS = ("alloc_scan", "alloc_commit", "integrate", "raycast")
 STAT_NAMES = ("probes", "new_keys", "swept", "nodes", "gets", "interps", "grads", "hits")
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -46,6 +46,7 @@ EXPORTS = {
     "se_hip_integrate": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_alloc_scan": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_new_keys_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "se_hip_set_new_keys_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "se_hip_alloc_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
     "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
@@ -162,6 +163,10 @@ class DenseSLAMPipeline:
         ptr, cap = C.c_void_p(), C.c_int64()
         self._check(self.lib.se_hip_new_keys_device(self._h, C.byref(ptr), C.byref(cap)))
         return ptr.value, cap.value
+
+    def set_new_keys_buffer(self, ptr: int, capacity_words: int, keepalive=None):
+        self._keys_keepalive = keepalive
+        self._check(self.lib.se_hip_set_new_keys_buffer(self._h, C.c_void_p(ptr), capacity_words))
 
     def alloc_commit(self, lists_ptr: int, nlists: int, stride_words: int):
         self._check(self.lib.se_hip_alloc_commit(self._h, C.c_void_p(lists_ptr), nlists, stride_words))

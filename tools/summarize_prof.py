@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (kernel-trace --stats CSV + PMC counter CSVs of separate passes) into a
+markdown summary: per-kernel launch count / average duration, and per-kernel per-launch counter means."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+OURS = ("k_alloc", "k_integrate", "k_raycast", "k_fill", "k_min_key", "k_zero_chain", "k_mm2meters")
+
+
+def short(name):
+    for o in OURS:
+        if o in name:
+            i = name.index(o)
+            j = name.find("(", i)
+            return name[i:j] if j > 0 else name[i:]
+    return name[:60]
+
+
+def find(sub, pattern):
+    return sorted(glob.glob(os.path.join(out_dir, sub, "**", pattern), recursive=True))
+
+
+print(f"# rocprofv3 summary `{tag}`  (bench.py --steps 50 --warmup 10, MI355X)\n")
+stats = find("trace", "*kernel_stats.csv")
+if stats:
+    print("## kernel trace (--kernel-trace --stats)\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---|---|---|---|---|---|")
+    with open(stats[0]) as fh:
+        for row in csv.DictReader(fh):
+            n = row.get("Name", "")
+            tot = float(row.get("TotalDurationNs", 0)) / 1e6
+            print(f"| {short(n)} | {row.get('Calls')} | {tot:.3f} | {float(row.get('AverageNs', 0)) / 1e3:.2f} | "
+                  f"{float(row.get('MinNs', 0)) / 1e3:.2f} | {float(row.get('MaxNs', 0)) / 1e3:.2f} | {row.get('Percentage')} |")
+    print()
+# steady-state durations from the raw trace: skip each kernel's first 14 launches (warm-up frames)
+trace = find("trace", "*kernel_trace.csv")
+if trace:
+    dur = defaultdict(list)
+    with open(trace[0]) as fh:
+        for row in csv.DictReader(fh):
+            dur[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    print("## steady state (launches after the 14 warm-up frames, from the raw kernel trace)\n")
+    print("| kernel | launches | avg us | p50 us | p95 us |")
+    print("|---|---|---|---|---|")
+    for k, v in sorted(dur.items()):
+        v.sort()
+        d = sorted(x[1] for x in v[14:]) or sorted(x[1] for x in v)
+        if not any(o in k for o in OURS):
+            continue
+        print(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {d[len(d) // 2] / 1e3:.2f} | {d[int(len(d) * 0.95)] / 1e3:.2f} |")
+    print()
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_cache"):
+    files = find(sub, "*counter_collection.csv")
+    if not files:
+        continue
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(files[0]) as fh:
+        for row in csv.DictReader(fh):
+            acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    print(f"## {sub}: mean counter value per launch (steady-state launches)\n")
+    names = sorted({c for k in acc for c in acc[k]})
+    print("| kernel | launches | " + " | ".join(names) + " |")
+    print("|---|---|" + "---|" * len(names))
+    for k in sorted(acc):
+        if not any(o in k for o in OURS):
+            continue
+        cells = []
+        n = 0
+        for c in names:
+            v = acc[k].get(c, [])
+            v = v[14:] if len(v) > 20 else v
+            n = max(n, len(v))
+            cells.append(f"{sum(v) / len(v):.4g}" if v else "-")
+        print(f"| {k} | {n} | " + " | ".join(cells) + " |")
+    print()
