@@ -128,9 +128,11 @@ int se_hip_enable_timing(se_hip_pipeline* p, int32_t on);
 int se_hip_get_timings(se_hip_pipeline* p, double ms_sum[SE_HIP_K_COUNT], int64_t launches[SE_HIP_K_COUNT], int32_t reset);
 /* Work counters behind the algorithmic-bytes figures of the roofline (instrumented kernel
  * variants, slower; off by default): out[0..7] = alloc probes, new keys, swept blocks, nodes,
- * get calls, interp calls, grad calls, ray hits -- accumulated since enabled / last read. */
+ * get calls, interp calls, grad calls, ray hits -- accumulated since enabled / last read;
+ * out[8..12] = raycast wave clocks (shader cycles): sum over waves of first-leaf search, march,
+ * gradient+store, max wave lifetime, sum of LDS staging; out[13..15] reserved. */
 int se_hip_enable_stats(se_hip_pipeline* p, int32_t on);
-int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[8], int32_t reset);
+int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[16], int32_t reset);
 
 #ifdef __cplusplus
 }

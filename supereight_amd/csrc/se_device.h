@@ -5,12 +5,19 @@
 //              (2^l)^3 uint32 grid, entry = 0 (absent) | id+1 | SE_PENDING (being created in the
 //              running alloc kernel).  Replaces the pointer octree of
 //              se_core/include/se/octree.hpp (fetch / fetch_octant / children walk).
+//   occ[]      occupancy bit pyramid: one bit per possible octant of every level, Morton order
+//              (the 8 children of an octant share one byte).  It is what the ray traversal walks;
+//              its top levels (37 KB for 512^3) are staged in LDS by the raycast kernel.
 //   vx[], vy[] SoA voxel planes, 512 consecutive floats per block, voxel index x + 8y + 64z
 //              (se_core/include/se/node.hpp:139-144).  SDF: x = tsdf, y = weight.
 //              OFusion: x = log-odds, y = last-update time (the reference stores y as double;
 //              every value it ever holds is a float, so float storage is lossless).
-//   bpos[]     packed block position in block units (x | y<<10 | z<<20), bactive[] the
-//              VoxelBlock::active_ flag.
+//   bpos[]     compact list of allocated blocks: packed position in block units
+//              (x | y<<10 | z<<20); bactive[] the VoxelBlock::active_ flag, indexed by voxel slot.
+//   Voxel slot of a block: pooled mode = its list index (pool of max_blocks bricks behind tab[]);
+//   dense mode (default while (N/8)^3 * 4 KB fits the HBM budget, i.e. N <= 2048 on 288 GB) = its
+//   linear grid index, every brick pre-initialised to initValue(): raycast addresses voxels
+//   straight from coordinates, one dependent memory access shorter per sample.
 //   nx[], ny[] Node::value_[8] of internal nodes, npos[]/nlevel[] their position and level.
 //
 // Arithmetic contract: IEEE-754 binary32, the operation order of the reference's source
@@ -24,12 +31,17 @@
 #define SE_MAX_LEVELS 12
 
 enum { C_BLOCKS = 0, C_NODES = 1, C_OVERFLOW = 2, C_COUNT = 8 };
-enum { S_PROBES = 0, S_NEWKEYS = 1, S_SWEPT = 2, S_NODES = 3, S_GETS = 4, S_INTERPS = 5, S_GRADS = 6, S_HITS = 7, S_COUNT = 8 };
+enum { S_PROBES = 0, S_NEWKEYS = 1, S_SWEPT = 2, S_NODES = 3, S_GETS = 4, S_INTERPS = 5, S_GRADS = 6, S_HITS = 7,
+       S_T_ITER = 8, S_T_MARCH = 9, S_T_GRAD = 10, S_T_WAVEMAX = 11, S_T_STAGE = 12, S_COUNT = 16 };
 
 struct DevMap {
   uint32_t* tab;
   uint32_t off[SE_MAX_LEVELS];
+  uint32_t* occ;                  // occupancy bit pyramid: level l has 8^l bits in Morton order at word woff[l]
+  uint32_t woff[SE_MAX_LEVELS + 1];
   int size, max_level, leaf_level;
+  int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
+  uint32_t leaf_off;              // = off[leaf_level]; kept separately so that hot kernels never index off[] dynamically
   float dim;
   float* vx;
   float* vy;
@@ -88,12 +100,46 @@ __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b 
 __device__ __forceinline__ float clampf(float f, float a, float b) { return std_max(a, std_min(f, b)); }
 __device__ __forceinline__ float sqf(float a) { return a * a; }
 
+__device__ __forceinline__ unsigned long long se_expand21_d(unsigned long long v) {
+  unsigned long long x = v & 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
 __device__ __forceinline__ uint32_t pack_pos(int x, int y, int z) { return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20); }
 __device__ __forceinline__ uint32_t tab_index(const DevMap& m, int l, int x, int y, int z) {
   return m.off[l] + (((((uint32_t)z << l) | (uint32_t)y) << l) | (uint32_t)x);
 }
+__device__ __forceinline__ uint32_t block_linear(const DevMap& m, int bx, int by, int bz) {
+  const int l = m.leaf_level;
+  return ((((uint32_t)bz << l) | (uint32_t)by) << l) | (uint32_t)bx;
+}
+// voxel slot of the block at list position `idx` with packed position `bp`
+__device__ __forceinline__ uint32_t block_slot(const DevMap& m, uint32_t idx, uint32_t bp) {
+  return m.dense ? block_linear(m, (int)(bp & 1023u), (int)((bp >> 10) & 1023u), (int)(bp >> 20)) : idx;
+}
+__device__ __forceinline__ uint32_t leaf_index(const DevMap& m, int bx, int by, int bz) {
+  const int l = m.leaf_level;
+  return m.leaf_off + (((((uint32_t)bz << l) | (uint32_t)by) << l) | (uint32_t)bx);
+}
 __device__ __forceinline__ uint32_t tab_index_packed(const DevMap& m, int l, uint32_t p) {
   return m.off[l] + (((((p >> 20) & 1023u) << l) | ((p >> 10) & 1023u)) << l | (p & 1023u));
+}
+// Morton code of an octant position (<= 10 bits per axis), x lowest
+__device__ __forceinline__ uint32_t morton30(int x, int y, int z) {
+  return (uint32_t)(se_expand21_d((unsigned long long)x) | (se_expand21_d((unsigned long long)y) << 1) | (se_expand21_d((unsigned long long)z) << 2));
+}
+// word offset of level l in occ[]: levels hold max(1, 8^l / 32) words; level l >= 3 starts at word
+// 2^(3l-7) (a quarter of its own size: the lower levels fit below it), levels 1 and 2 at words 0
+// and 1.  A closed form because l is a per-lane value in the ray traversal (indexing the by-value
+// DevMap arrays with a vector index would spill them to scratch).
+__host__ __device__ __forceinline__ uint32_t occ_woff(int l) { return l >= 3 ? 1u << (3 * l - 7) : (uint32_t)(l - 1); }
+__device__ __forceinline__ void occ_set(const DevMap& m, int l, int x, int y, int z) {
+  const uint32_t code = morton30(x, y, z);
+  atomicOr(&m.occ[m.woff[l] + (code >> 5)], 1u << (code & 31u));
 }
 __device__ __forceinline__ bool in_volume(const DevMap& m, int x, int y, int z) {
   return (unsigned)x < (unsigned)m.size && (unsigned)y < (unsigned)m.size && (unsigned)z < (unsigned)m.size;

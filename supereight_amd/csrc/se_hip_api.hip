@@ -66,6 +66,9 @@ struct se_hip_pipeline {
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
+  size_t occ_words = 0;
+  size_t slots = 0;
+  int ray_cache_levels = -1;  // -1: choose automatically
   float* depth_own = nullptr;       // width*height floats
   const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
   unsigned short* depth_mm = nullptr;
@@ -191,6 +194,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->row_begin = cfg->row_begin;
   p->row_end = (cfg->row_end > cfg->row_begin) ? cfg->row_end : cfg->height;
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
+  if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
   p->max_level = ilog2(N);
   p->leaf_level = p->max_level - 3;
   DevMap& m = p->map;
@@ -199,9 +203,24 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   for (int l = 0; l < SE_MAX_LEVELS; ++l) m.off[l] = 0;
   for (int l = 1; l <= p->leaf_level; ++l) { m.off[l] = (uint32_t)off; off += (size_t)1 << (3 * l); }
   p->tab_entries = off;
+  m.leaf_off = m.off[p->leaf_level];
+  for (int l = 0; l <= SE_MAX_LEVELS; ++l) m.woff[l] = 0;
+  for (int l = 1; l <= p->leaf_level + 1; ++l) m.woff[l] = occ_woff(l);
+  p->occ_words = (size_t)occ_woff(p->leaf_level) + std::max<size_t>(1, ((size_t)1 << (3 * p->leaf_level)) / 32);
   const size_t cells = (size_t)1 << (3 * p->leaf_level);
-  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : std::min(cells, (size_t)1 << 21);
+  // Dense mode (default): one 4 KB brick slot per cell of the block grid, addressed by position --
+  // 1 GiB at 512^3, 8 GiB at 1024^3, 64 GiB at 2048^3 of the 288 GB; bricks are pre-set to
+  // initValue() so an unallocated voxel reads exactly what the reference's tree walk returns.
+  // Pooled mode (max_blocks > 0, or a grid that does not fit): max_blocks bricks behind the index.
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  bool dense = cfg->max_blocks <= 0 && cells * 4096 <= free_b / 3;
+  if (const char* ev = std::getenv("SE_HIP_DENSE")) dense = std::atoi(ev) != 0 && cells * 4096 <= free_b / 2;
+  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : (dense ? cells : std::min(cells, (size_t)1 << 21));
   cap = std::min(cap, cells);
+  m.dense = dense ? 1 : 0;
+  const size_t slots = dense ? cells : cap;   // voxel bricks / active flags
+  p->slots = slots;
   size_t capn = std::min(off - cells + 1, cap / 2 + 4096);  // internal nodes (+ root)
   m.cap_blocks = (uint32_t)cap; m.cap_nodes = (uint32_t)capn;
   m.cap_keys = cap + capn;
@@ -214,10 +233,11 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (e != hipSuccess) return bail(e, "hipStreamCreate");
   p->own_stream = true;
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
-  ALLOC(m.vx, cap * 512 * sizeof(float));
-  ALLOC(m.vy, cap * 512 * sizeof(float));
+  ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
+  ALLOC(m.vx, slots * 512 * sizeof(float));
+  ALLOC(m.vy, slots * 512 * sizeof(float));
   ALLOC(m.bpos, cap * sizeof(uint32_t));
-  ALLOC(m.bactive, cap);
+  ALLOC(m.bactive, slots);
   ALLOC(m.nx, capn * 8 * sizeof(float));
   ALLOC(m.ny, capn * 8 * sizeof(float));
   ALLOC(m.npos, capn * sizeof(uint32_t));
@@ -235,8 +255,9 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (e != hipSuccess) return bail(e, "hipHostMalloc");
 
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, cap * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.bactive, 0, cap, p->stream);
+  hipMemsetAsync(m.bactive, 0, slots, p->stream);
   hipMemsetAsync(m.npos, 0, capn * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.nlevel, 0, capn, p->stream);
   hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
@@ -247,8 +268,8 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   // node 0 = root (Octree::init, se_core/include/se/octree.hpp:425-437): level 0, side = size
   const uint32_t ctr0[C_COUNT] = {0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u};
   hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
-  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, p->stream, m.vx, m.init_x, cap * 512);
-  hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, p->stream, m.vy, m.init_y, cap * 512);
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vx, m.init_x, slots * 512);
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vy, m.init_y, slots * 512);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.nx, m.init_x, capn * 8);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.ny, m.init_y, capn * 8);
   if (cfg->field_type == SE_HIP_FIELD_OFUSION) {
@@ -274,7 +295,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
+  void* ptrs[] = {m.occ, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain};
   for (void* q : ptrs) if (q) hipFree(q);
   if (p->ctr_host) hipHostFree(p->ctr_host);
@@ -476,18 +497,40 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   a.epsilon = exp2f(-(float)p->max_level);  // ray_iterator.hpp:63
   a.min_scale = 23 - p->leaf_level;         // ray_iterator.hpp:62
   a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
-  const int tiles = ((a.W + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_ROWS")) {  // diagnostic: raycast only rows [b,e)
+    int b = 0, e = 0;
+    if (std::sscanf(ev, "%d,%d", &b, &e) == 2 && b >= 0 && e > b && e <= a.H) { a.row_begin = b; a.row_end = e; }
+  }
+  // occupancy levels staged in LDS: levels 1..5 (4.7 KB; measured: level 6 = +32 KB costs more
+  // occupancy and staging time than the leaf-level bit tests it saves) unless overridden
+  int cl = p->ray_cache_levels >= 0 ? p->ray_cache_levels : 5;
+  cl = std::min(cl, p->leaf_level);
+  a.cache_levels = cl;
+  // staged region = words [0, end of level cl)
+  a.cache_words = cl > 0 ? (int)(occ_woff(cl) + std::max<size_t>(1, ((size_t)1 << (3 * cl)) / 32)) : 1;
+  a.stack_depth = p->leaf_level;
+  // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
+  // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
+  a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
+  const size_t smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG) * sizeof(uint32_t);
+  const int tiles = ((a.W + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
   const dim3 grid((tiles + 3) / 4), block(SE_WG);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   {
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
-    if (sdf) {
-      if (p->stats) hipLaunchKernelGGL((k_raycast<false, true>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
-      else hipLaunchKernelGGL((k_raycast<false, false>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
-    } else {
-      if (p->stats) hipLaunchKernelGGL((k_raycast<true, true>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
-      else hipLaunchKernelGGL((k_raycast<true, false>), grid, block, 0, p->stream, m, a, p->vertex, p->normal);
+#define SE_RAY(OF, ST, DN) hipLaunchKernelGGL((k_raycast<OF, ST, DN>), grid, block, smem, p->stream, m, a, p->vertex, p->normal)
+    const int variant = (sdf ? 0 : 4) | (p->stats ? 2 : 0) | (m.dense ? 1 : 0);
+    switch (variant) {
+      case 0: SE_RAY(false, false, false); break;
+      case 1: SE_RAY(false, false, true); break;
+      case 2: SE_RAY(false, true, false); break;
+      case 3: SE_RAY(false, true, true); break;
+      case 4: SE_RAY(true, false, false); break;
+      case 5: SE_RAY(true, false, true); break;
+      case 6: SE_RAY(true, true, false); break;
+      case 7: SE_RAY(true, true, true); break;
     }
+#undef SE_RAY
   }
   HIP_TRY(hipGetLastError());
   return 1;
@@ -531,24 +574,46 @@ int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float*
   const size_t n = p->ctr_host[C_BLOCKS];
   if (n == 0) return SE_HIP_OK;
   std::vector<uint32_t> pos(n);
-  std::vector<uint8_t> act(n);
   HIP_TRY(hipMemcpy(pos.data(), p->map.bpos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(act.data(), p->map.bactive, n, hipMemcpyDeviceToHost));
+  const int L = p->leaf_level;
+  auto slot_of = [&](size_t i) -> size_t {
+    if (!p->map.dense) return i;
+    const uint32_t bp = pos[i];
+    return ((((size_t)(bp >> 20) << L) | ((bp >> 10) & 1023u)) << L) | (bp & 1023u);
+  };
+  std::vector<uint8_t> act_all(p->slots);
+  HIP_TRY(hipMemcpy(act_all.data(), p->map.bactive, p->slots, hipMemcpyDeviceToHost));
   std::vector<unsigned long long> key(n);
   for (size_t i = 0; i < n; ++i)
     key[i] = se_make_key(pos[i] & 1023u, (pos[i] >> 10) & 1023u, pos[i] >> 20, p->leaf_level, p->max_level);
   std::vector<size_t> order(n);
   std::iota(order.begin(), order.end(), 0);
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
-  std::vector<float> hx, hy;
-  if (x) { hx.resize(n * 512); HIP_TRY(hipMemcpy(hx.data(), p->map.vx, n * 512 * sizeof(float), hipMemcpyDeviceToHost)); }
-  if (y) { hy.resize(n * 512); HIP_TRY(hipMemcpy(hy.data(), p->map.vy, n * 512 * sizeof(float), hipMemcpyDeviceToHost)); }
+  std::vector<uint32_t> slots_sorted(n);
   for (size_t i = 0; i < n; ++i) {
     const size_t s = order[i];
+    const size_t slot = slot_of(s);
+    slots_sorted[i] = (uint32_t)slot;
     if (coords) { coords[3 * i] = (int)(pos[s] & 1023u) << 3; coords[3 * i + 1] = (int)((pos[s] >> 10) & 1023u) << 3; coords[3 * i + 2] = (int)(pos[s] >> 20) << 3; }
-    if (active) active[i] = act[s];
-    if (x) std::memcpy(x + i * 512, hx.data() + s * 512, 512 * sizeof(float));
-    if (y) std::memcpy(y + i * 512, hy.data() + s * 512, 512 * sizeof(float));
+    if (active) active[i] = act_all[slot];
+  }
+  if (x || y) {
+    uint32_t* d_slots = nullptr;
+    float* d_pack = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_slots, n * sizeof(uint32_t)));
+    hipError_t e2 = hipMalloc((void**)&d_pack, n * 512 * sizeof(float));
+    if (e2 != hipSuccess) { hipFree(d_slots); return fail(SE_HIP_E_DEVICE, "hipMalloc (download staging)"); }
+    hipMemcpyAsync(d_slots, slots_sorted.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, p->stream);
+    for (int plane = 0; plane < 2; ++plane) {
+      float* dst = plane ? y : x;
+      if (!dst) continue;
+      hipLaunchKernelGGL(k_gather_bricks, dim3(2048), dim3(SE_WG), 0, p->stream, plane ? p->map.vy : p->map.vx, d_slots, n, d_pack);
+      hipMemcpyAsync(dst, d_pack, n * 512 * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+    }
+    hipError_t e3 = hipStreamSynchronize(p->stream);
+    hipFree(d_slots);
+    hipFree(d_pack);
+    if (e3 != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("download_blocks: ") + hipGetErrorString(e3));
   }
   return SE_HIP_OK;
 }
@@ -605,14 +670,14 @@ int se_hip_enable_stats(se_hip_pipeline* p, int32_t on) {
   return SE_HIP_OK;
 }
 
-int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[8], int32_t reset) {
+int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[16], int32_t reset) {
   if (int r = check(p)) return r;
   unsigned long long h[S_COUNT];
   HIP_TRY(hipMemcpyAsync(h, p->map.stats, sizeof h, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (int r = fetch_counters(p)) return r;
   h[S_NODES] = p->ctr_host[C_NODES];
-  for (int i = 0; i < 8; ++i) out[i] = h[i];
+  for (int i = 0; i < S_COUNT; ++i) out[i] = h[i];
   if (reset) HIP_TRY(hipMemsetAsync(p->map.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream));
   return SE_HIP_OK;
 }

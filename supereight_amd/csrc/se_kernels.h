@@ -6,7 +6,8 @@
 #include "se_device.h"
 
 #define SE_WG 256
-#define SE_STACK 10  // ray stack slots = octree levels above the leaves (<= 9 for 4096^3)
+#define SE_SPEC 4     // SDF march: samples fetched per memory round trip
+#define SE_SPEC_OF 4  // OFusion march: samples fetched per memory round trip
 
 // ------------------------------------------------------------------------------------------
 // index insertion (replaces Octree::allocate / allocate_level, se_core/include/se/octree.hpp:792-856)
@@ -23,6 +24,7 @@ __device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, 
     if (nid >= m.cap_nodes) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); break; }
     m.npos[nid] = pack_pos(x, y, z);
     m.nlevel[nid] = (uint8_t)l;
+    occ_set(m, l, x, y, z);
     atomicExch(e, nid + 1u);
   }
 }
@@ -34,16 +36,20 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
   const uint32_t old = atomicCAS(e, 0u, SE_PENDING);
   if (old != 0u) return false;
   if (level == m.leaf_level) {
-    const uint32_t bid = atomicAdd(&m.ctr[C_BLOCKS], 1u);
-    if (bid >= m.cap_blocks) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
-    m.bpos[bid] = pack_pos(x, y, z);
-    m.bactive[bid] = 1;  // allocate_level: active(true), octree.hpp:841
-    atomicExch(e, bid + 1u);
+    const uint32_t idx = atomicAdd(&m.ctr[C_BLOCKS], 1u);
+    if (idx >= m.cap_blocks) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
+    const uint32_t bp = pack_pos(x, y, z);
+    const uint32_t slot = block_slot(m, idx, bp);
+    m.bpos[idx] = bp;
+    m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
+    occ_set(m, level, x, y, z);
+    atomicExch(e, slot + 1u);
   } else {
     const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
     if (nid >= m.cap_nodes) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
     m.npos[nid] = pack_pos(x, y, z);
     m.nlevel[nid] = (uint8_t)level;
+    occ_set(m, level, x, y, z);
     atomicExch(e, nid + 1u);
   }
   se_ensure_ancestors(m, level, x, y, z);
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_scan_sdf(DevMap m, const float*
           ++probes;
           if (bx != lbx || by != lby || bz != lbz) {
             lbx = bx; lby = by; lbz = bz;
-            const uint32_t e = m.tab[tab_index(m, m.leaf_level, bx, by, bz)];
+            const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
             if (e == 0u) {
               if (se_insert_octant(m, m.leaf_level, bx, by, bz)) { se_append_key(m, m.leaf_level, bx, by, bz); ++newk; }
             } else if (e != SE_PENDING) {
@@ -364,10 +370,11 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
-    if (!m.bactive[b] && !se_in_frustum(a, bx, by, bz)) continue;
+    const uint32_t slot = block_slot(m, b, bp);
+    if (!m.bactive[slot] && !se_in_frustum(a, bx, by, bz)) continue;
     if (STATS && lane == 0) ++swept;
-    float* px = m.vx + (size_t)b * 512 + lane;
-    float* py = m.vy + (size_t)b * 512 + lane;
+    float* px = m.vx + (size_t)slot * 512 + lane;
+    float* py = m.vy + (size_t)slot * 512 + lane;
     float vx[8], vy[8];
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
       if (dirty) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
     const bool any = __ballot(visible) != 0ull;
-    if (lane == 0) m.bactive[b] = any ? 1 : 0;  // block->active(is_visible)
+    if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
   }
   if (STATS && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
   for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG)
@@ -415,16 +422,32 @@ struct RayArgs {
   float epsilon;     // exp2f(-log2(size))
   int min_scale;     // CAST_STACK_DEPTH - log2(size / 8)
   int W, H, row_begin, row_end;
+  int cache_levels;  // occupancy levels 1..cache_levels are staged in LDS
+  int cache_words;   // = woff[cache_levels + 1] - woff[1]
+  int stack_depth;   // ray stack slots (= leaf level)
+  int xcd_swizzle;
 };
 
 struct BlkCache { int bx, by, bz; uint32_t e; };
+// voxel_traits<T>::initValue() / empty() as register values.  Reading them through the by-value
+// DevMap inside `cond ? load : m.init_x` lets the compiler fold both into one FLAT load of a
+// selected address (and park the constants in scratch to have an address).
+struct FieldConst { float init_x, init_y, empty_x; };
+__device__ __forceinline__ FieldConst se_field_const(const DevMap& m) {
+  FieldConst f = {m.init_x, m.init_y, m.empty_x};
+  asm volatile("" : "+s"(f.init_x), "+s"(f.init_y), "+s"(f.empty_x));
+  return f;
+}
 
-// leaf-grid entry of the block holding voxel (x,y,z); 0 if outside the volume or not allocated
+// slot+1 of the block holding voxel (x,y,z); 0 if outside the volume or (pooled mode) not allocated.
+// Dense mode needs no memory access: every brick of the grid exists and unallocated ones hold initValue().
+template <bool DENSE>
 __device__ __forceinline__ uint32_t se_block_of(const DevMap& m, int x, int y, int z, BlkCache& c) {
   if (!in_volume(m, x, y, z)) return 0u;
   const int bx = x >> 3, by = y >> 3, bz = z >> 3;
+  if (DENSE) return block_linear(m, bx, by, bz) + 1u;
   if (bx == c.bx && by == c.by && bz == c.bz) return c.e;
-  const uint32_t e = m.tab[tab_index(m, m.leaf_level, bx, by, bz)];
+  const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
   c.bx = bx; c.by = by; c.bz = bz; c.e = e;
   return e;
 }
@@ -432,78 +455,118 @@ __device__ __forceinline__ size_t se_voxel_index(uint32_t e, int x, int y, int z
   return (size_t)(e - 1u) * 512 + (size_t)((x & 7) + ((y & 7) << 3) + ((z & 7) << 6));
 }
 
+// Memory-level parallelism is what the raycast kernel lives on: a wave is a chain of dependent L2
+// round trips, so interp and grad are written as "all block look-ups -> all voxel loads -> math"
+// with unconditional loads (a missing block reads a dummy address and the value is replaced
+// afterwards) instead of one branch per sample.
+
+// leaf-grid entry of block (bx,by,bz) or 0 outside the volume; `hint` is a block whose entry is
+// already known (the block of the preceding get) and saves the load.
+template <bool DENSE>
+__device__ __forceinline__ uint32_t se_block_entry(const DevMap& m, int bx, int by, int bz, const BlkCache& hint) {
+  const int nb = m.size >> 3;
+  uint32_t e = 0u;
+  if (DENSE) return ((unsigned)bx < (unsigned)nb && (unsigned)by < (unsigned)nb && (unsigned)bz < (unsigned)nb) ? block_linear(m, bx, by, bz) + 1u : 0u;
+  if (bx == hint.bx && by == hint.by && bz == hint.bz) e = hint.e;
+  else if ((unsigned)bx < (unsigned)nb && (unsigned)by < (unsigned)nb && (unsigned)bz < (unsigned)nb) e = m.tab[leaf_index(m, bx, by, bz)];
+  return e;
+}
+
 // Octree::interp (octree.hpp:541-563) with gather_points (interp_gather.hpp:107-237): every corner
 // is read from the block that contains it; a missing block yields empty().x, the all-cross case
 // goes through get_fine -> initValue().x (identical values for both field types).
-__device__ __forceinline__ float se_interp(const DevMap& m, f3 pos, BlkCache& c) {
+template <bool DENSE>
+__device__ __forceinline__ float se_interp(const DevMap& m, const FieldConst fc, f3 pos, BlkCache& c) {
   const float flx = floorf(pos.x), fly = floorf(pos.y), flz = floorf(pos.z);
   const int bx = cvt_i32(flx), by = cvt_i32(fly), bz = cvt_i32(flz);
   const float fx = pos.x - flx, fy = pos.y - fly, fz = pos.z - flz;
   const int lx = max(bx, 0), ly = max(by, 0), lz = max(bz, 0);
-  const int cm = (((lx & 7) == 7) << 2) | (((ly & 7) == 7) << 1) | ((lz & 7) == 7);
+  const bool cx = (lx & 7) == 7, cy = (ly & 7) == 7, cz = (lz & 7) == 7;
+  const float missing = (cx && cy && cz) ? fc.init_x : fc.empty_x;
+  // phase 1: the (up to 8) blocks the cell touches
+  uint32_t e[8];
+  e[0] = se_block_entry<DENSE>(m, lx >> 3, ly >> 3, lz >> 3, c);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const bool need = (!(k & 1) || cx) && (!(k & 2) || cy) && (!(k & 4) || cz);
+    e[k] = 0u;
+    if (need) e[k] = se_block_entry<DENSE>(m, (lx + (k & 1)) >> 3, (ly + ((k >> 1) & 1)) >> 3, (lz + (k >> 2)) >> 3, c);
+  }
+  // phase 2: the 8 corner values
   float p[8];
-  if (cm == 0) {
-    const uint32_t e = se_block_of(m, lx, ly, lz, c);
-    if (e == 0u) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) p[k] = m.empty_x;
-    } else {
-      const float* b = m.vx + se_voxel_index(e, lx, ly, lz);
-      p[0] = b[0]; p[1] = b[1]; p[2] = b[8]; p[3] = b[9]; p[4] = b[64]; p[5] = b[65]; p[6] = b[72]; p[7] = b[73];
-    }
-  } else {
-    const float missing = (cm == 7) ? m.init_x : m.empty_x;
+  for (int k = 0; k < 8; ++k) {
+    const int kk = (cx ? (k & 1) : 0) | (cy ? (k & 2) : 0) | (cz ? (k & 4) : 0);
+    uint32_t ek = e[0];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int x = lx + (k & 1), y = ly + ((k >> 1) & 1), z = lz + (k >> 2);
-      const uint32_t e = se_block_of(m, x, y, z, c);
-      p[k] = e ? m.vx[se_voxel_index(e, x, y, z)] : missing;
-    }
+    for (int j = 1; j < 8; ++j) ek = (kk == j) ? e[j] : ek;
+    const int x = lx + (k & 1), y = ly + ((k >> 1) & 1), z = lz + (k >> 2);
+    const size_t vi = ek ? se_voxel_index(ek, x, y, z) : 0;
+    const float v = m.vx[vi];
+    p[k] = ek ? v : missing;
   }
   return (((p[0] * (1 - fx) + p[1] * fx) * (1 - fy) + (p[2] * (1 - fx) + p[3] * fx) * fy) * (1 - fz) +
           ((p[4] * (1 - fx) + p[5] * fx) * (1 - fy) + (p[6] * (1 - fx) + p[7] * fx) * fy) * fz);
 }
 
-// value of voxel (x,y,z) as the cached Octree::get(x,y,z,block) sees it: stored value or initValue().x
-__device__ __forceinline__ float se_sample_x(const DevMap& m, int x, int y, int z, BlkCache& c) {
-  const uint32_t e = se_block_of(m, x, y, z, c);
-  return e ? m.vx[se_voxel_index(e, x, y, z)] : m.init_x;
-}
-
-// Octree::grad (octree.hpp:652-737), same term order
-__device__ __forceinline__ f3 se_grad(const DevMap& m, f3 pos, BlkCache& c) {
+// Octree::grad (octree.hpp:652-737), same term order.  The 48 get() calls of the reference touch
+// 32 distinct voxels: per axis the four clamped coordinates {base-1, base, base+1, base+2} (indices
+// 0..3 below; "lower" = 1, "upper" = 2), every sample having at least two axes on a central index.
+// They lie in at most 2x2x2 blocks.  A voxel of a missing block reads as initValue().x (the cached
+// Octree::get(x,y,z,block) falls back to the tree walk, octree.hpp:379-408).
+template <bool DENSE>
+__device__ __forceinline__ f3 se_grad(const DevMap& m, const FieldConst fc, f3 pos, BlkCache& c) {
   const float flx = floorf(pos.x), fly = floorf(pos.y), flz = floorf(pos.z);
   const int bx = cvt_i32(flx), by = cvt_i32(fly), bz = cvt_i32(flz);
   const float fx = pos.x - flx, fy = pos.y - fly, fz = pos.z - flz;
   const int hi = m.size - 1;
-  const int llx = max(bx - 1, 0), lly = max(by - 1, 0), llz = max(bz - 1, 0);
-  const int lux = max(bx, 0), luy = max(by, 0), luz = max(bz, 0);
-  const int ulx = min(bx + 1, hi), uly = min(by + 1, hi), ulz = min(bz + 1, hi);
-  const int uux = min(bx + 2, hi), uuy = min(by + 2, hi), uuz = min(bz + 2, hi);
-  const int lox = lux, loy = luy, loz = luz, upx = ulx, upy = uly, upz = ulz;
-#define G(X, Y, Z) se_sample_x(m, X, Y, Z, c)
+  const int X[4] = {max(bx - 1, 0), max(bx, 0), min(bx + 1, hi), min(bx + 2, hi)};
+  const int Y[4] = {max(by - 1, 0), max(by, 0), min(by + 1, hi), min(by + 2, hi)};
+  const int Z[4] = {max(bz - 1, 0), max(bz, 0), min(bz + 1, hi), min(bz + 2, hi)};
+  const int xb0 = X[0] >> 3, yb0 = Y[0] >> 3, zb0 = Z[0] >> 3;
+  const int xb1 = X[3] >> 3, yb1 = Y[3] >> 3, zb1 = Z[3] >> 3;
+  // phase 1: entries of the 2x2x2 candidate blocks (coincident ones are the same cache line)
+  uint32_t e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = se_block_entry<DENSE>(m, (k & 1) ? xb1 : xb0, (k & 2) ? yb1 : yb0, (k & 4) ? zb1 : zb0, c);
+  // phase 2: the 32 voxels
+  float V[4][4][4];
+#pragma unroll
+  for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+    for (int yi = 0; yi < 4; ++yi)
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const int central = (xi == 1 || xi == 2) + (yi == 1 || yi == 2) + (zi == 1 || zi == 2);
+        if (central < 2) continue;
+        const int x = X[xi], y = Y[yi], z = Z[zi];
+        const int kk = ((x >> 3) != xb0 ? 1 : 0) | ((y >> 3) != yb0 ? 2 : 0) | ((z >> 3) != zb0 ? 4 : 0);
+        uint32_t ek = e[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) ek = (kk == j) ? e[j] : ek;
+        const size_t vi = ek ? se_voxel_index(ek, x, y, z) : 0;
+        const float v = m.vx[vi];
+        V[zi][yi][xi] = ek ? v : fc.init_x;
+      }
   f3 g;
-  g.x = (((G(ulx, loy, loz) - G(llx, loy, loz)) * (1 - fx) + (G(uux, loy, loz) - G(lux, loy, loz)) * fx) * (1 - fy) +
-         ((G(ulx, upy, loz) - G(llx, upy, loz)) * (1 - fx) + (G(uux, upy, loz) - G(lux, upy, loz)) * fx) * fy) * (1 - fz) +
-        (((G(ulx, loy, upz) - G(llx, loy, upz)) * (1 - fx) + (G(uux, loy, upz) - G(lux, loy, upz)) * fx) * (1 - fy) +
-         ((G(ulx, upy, upz) - G(llx, upy, upz)) * (1 - fx) + (G(uux, upy, upz) - G(lux, upy, upz)) * fx) * fy) * fz;
-  g.y = (((G(lox, uly, loz) - G(lox, lly, loz)) * (1 - fx) + (G(upx, uly, loz) - G(upx, lly, loz)) * fx) * (1 - fy) +
-         ((G(lox, uuy, loz) - G(lox, luy, loz)) * (1 - fx) + (G(upx, uuy, loz) - G(upx, luy, loz)) * fx) * fy) * (1 - fz) +
-        (((G(lox, uly, upz) - G(lox, lly, upz)) * (1 - fx) + (G(upx, uly, upz) - G(upx, lly, upz)) * fx) * (1 - fy) +
-         ((G(lox, uuy, upz) - G(lox, luy, upz)) * (1 - fx) + (G(upx, uuy, upz) - G(upx, luy, upz)) * fx) * fy) * fz;
-  g.z = (((G(lox, loy, ulz) - G(lox, loy, llz)) * (1 - fx) + (G(upx, loy, ulz) - G(upx, loy, llz)) * fx) * (1 - fy) +
-         ((G(lox, upy, ulz) - G(lox, upy, llz)) * (1 - fx) + (G(upx, upy, ulz) - G(upx, upy, llz)) * fx) * fy) * (1 - fz) +
-        (((G(lox, loy, uuz) - G(lox, loy, luz)) * (1 - fx) + (G(upx, loy, uuz) - G(upx, loy, luz)) * fx) * (1 - fy) +
-         ((G(lox, upy, uuz) - G(lox, upy, luz)) * (1 - fx) + (G(upx, upy, uuz) - G(upx, upy, luz)) * fx) * fy) * fz;
-#undef G
+  g.x = (((V[1][1][2] - V[1][1][0]) * (1 - fx) + (V[1][1][3] - V[1][1][1]) * fx) * (1 - fy) +
+         ((V[1][2][2] - V[1][2][0]) * (1 - fx) + (V[1][2][3] - V[1][2][1]) * fx) * fy) * (1 - fz) +
+        (((V[2][1][2] - V[2][1][0]) * (1 - fx) + (V[2][1][3] - V[2][1][1]) * fx) * (1 - fy) +
+         ((V[2][2][2] - V[2][2][0]) * (1 - fx) + (V[2][2][3] - V[2][2][1]) * fx) * fy) * fz;
+  g.y = (((V[1][2][1] - V[1][0][1]) * (1 - fx) + (V[1][2][2] - V[1][0][2]) * fx) * (1 - fy) +
+         ((V[1][3][1] - V[1][1][1]) * (1 - fx) + (V[1][3][2] - V[1][1][2]) * fx) * fy) * (1 - fz) +
+        (((V[2][2][1] - V[2][0][1]) * (1 - fx) + (V[2][2][2] - V[2][0][2]) * fx) * (1 - fy) +
+         ((V[2][3][1] - V[2][1][1]) * (1 - fx) + (V[2][3][2] - V[2][1][2]) * fx) * fy) * fz;
+  g.z = (((V[2][1][1] - V[0][1][1]) * (1 - fx) + (V[2][1][2] - V[0][1][2]) * fx) * (1 - fy) +
+         ((V[2][2][1] - V[0][2][1]) * (1 - fx) + (V[2][2][2] - V[0][2][2]) * fx) * fy) * (1 - fz) +
+        (((V[3][1][1] - V[1][1][1]) * (1 - fx) + (V[3][1][2] - V[1][1][2]) * fx) * (1 - fy) +
+         ((V[3][2][1] - V[1][2][1]) * (1 - fx) + (V[3][2][2] - V[1][2][2]) * fx) * fy) * fz;
   return g;  // the caller applies (0.5f * dim / size)
 }
 
-// ray_iterator constructor + first next() (se_core/include/se/ray_iterator.hpp:53-226) on the
-// index pyramid.  The node pointer of the reference becomes the packed position of the parent at
-// its level; its stack lives in LDS, one column per lane.  Returns tcmin(); *tmax_out = tmax().
-__device__ __forceinline__ float se_first_leaf(const DevMap& m, const RayArgs& a, f3 origin, f3 direction, float* tmax_out,
-                                               uint32_t (*s_par)[SE_WG], float (*s_tmax)[SE_WG]) {
+struct RaySpan { float tcmin, tmax; };
+__device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs& a, f3 origin, f3 direction,
+                                                 const uint32_t* s_occ, uint32_t* s_par, float* s_tmax) {
   const int tid = threadIdx.x;
   f3 pos = {1.0f, 1.0f, 1.0f};
   int idx = 0;
@@ -527,29 +590,38 @@ __device__ __forceinline__ float se_first_leaf(const DevMap& m, const RayArgs& a
   float h = t_max;
   t_min = fmaxf(t_min, a.nearp / m.dim);
   t_max = fminf(t_max, a.farp / m.dim);
-  *tmax_out = t_max * m.dim;
+  const float tmax_m = t_max * m.dim;
   if (1.5f * t_coef.x - t_bias.x > t_min) { idx ^= 1; pos.x = 1.5f; }
   if (1.5f * t_coef.y - t_bias.y > t_min) { idx ^= 2; pos.y = 1.5f; }
   if (1.5f * t_coef.z - t_bias.z > t_min) { idx ^= 4; pos.z = 1.5f; }
-#pragma unroll
-  for (int i = 0; i < SE_STACK; ++i) { s_par[i][tid] = 0u; s_tmax[i][tid] = 0.f; }
+  for (int i = 0; i < a.stack_depth; ++i) { s_par[i * SE_WG + tid] = 0u; s_tmax[i * SE_WG + tid] = 0.f; }
 
   f3 t_corner = {0.f, 0.f, 0.f};
   float tc_max = 0.f;
+  uint32_t gw_index = 0xFFFFFFFFu, gw_word = 0u;  // last occupancy word fetched from global memory
   for (int guard = 0; guard < 4096 && scale < 23; ++guard) {
     t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
     tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
     const int cidx = idx ^ octant_mask ^ 7;
     const int clevel = 23 - scale;  // level of the child
-    const uint32_t child = (parent << 1) | (uint32_t)(cidx & 1) | ((uint32_t)((cidx >> 1) & 1) << 10) | ((uint32_t)(cidx >> 2) << 20);
-    const bool exists = m.tab[tab_index_packed(m, clevel, child)] != 0u;
+    const uint32_t child = (parent << 3) | (uint32_t)cidx;
+    const uint32_t w = occ_woff(clevel) + (child >> 5);   // woff(1) == 0: LDS index == global index
+    // two separate loads (LDS / global): selecting between the pointers would force a flat load
+    uint32_t word = s_occ[min(w, (uint32_t)(a.cache_words - 1))];
+    asm volatile("" : "+v"(word));  // keep the LDS load an LDS load
+    if (clevel > a.cache_levels) {
+      // the 8 children of an octant share one byte: sibling tests reuse the word already fetched
+      if (w != gw_index) { gw_index = w; gw_word = m.occ[w]; }
+      word = gw_word;
+    }
+    const bool exists = (word >> (child & 31u)) & 1u;
     if (scale == a.min_scale && exists) break;  // leaf found: t_min is its entry distance
     if (exists && t_min <= t_max) {
       // descend (ray_iterator.hpp:172-199)
       const float tv_max = fminf(t_max, tc_max);
       const float half = scale_exp2 * 0.5f;
       const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
-      if (tc_max < h) { s_par[22 - scale][tid] = parent; s_tmax[22 - scale][tid] = t_max; }
+      if (tc_max < h) { s_par[(22 - scale) * SE_WG + tid] = parent; s_tmax[(22 - scale) * SE_WG + tid] = t_max; }
       h = tc_max;
       parent = child;
       idx = 0;
@@ -579,7 +651,7 @@ __device__ __forceinline__ float se_first_leaf(const DevMap& m, const RayArgs& a
       scale = (__float_as_int((float)differing_bits) >> 23) - 127;
       scale_exp2 = __int_as_float((scale - 23 + 127) << 23);
       const int slot = 22 - scale;
-      if (slot >= 0 && slot < SE_STACK) { parent = s_par[slot][tid]; t_max = s_tmax[slot][tid]; }
+      if (slot >= 0 && slot < a.stack_depth) { parent = s_par[slot * SE_WG + tid]; t_max = s_tmax[slot * SE_WG + tid]; }
       if (scale >= 0 && scale < 31) {
         const int shx = __float_as_int(pos.x) >> scale;
         const int shy = __float_as_int(pos.y) >> scale;
@@ -592,17 +664,31 @@ __device__ __forceinline__ float se_first_leaf(const DevMap& m, const RayArgs& a
       h = 0.0f;
     }
   }
-  return t_min * m.dim;
+  return {t_min * m.dim, tmax_m};
 }
 
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
-template <bool OFUSION, bool STATS>
+template <bool OFUSION, bool STATS, bool DENSE>
 __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
-  __shared__ uint32_t s_par[SE_STACK][SE_WG];
-  __shared__ float s_tmax[SE_STACK][SE_WG];
+  // LDS: [occupancy words of levels 1..cache_levels][ray stack: parent codes][ray stack: t_max]
+  extern __shared__ uint32_t smem[];
+  uint32_t* s_occ = smem;
+  uint32_t* s_par = smem + a.cache_words;
+  float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG);
+  const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int i = threadIdx.x; i < a.cache_words; i += SE_WG) s_occ[i] = m.occ[i];
+  __syncthreads();
+  const unsigned long long tk1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long tk2 = tk1, tk3 = tk1;
+  const FieldConst fc = se_field_const(m);
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * (SE_WG / 64) + (threadIdx.x >> 6);
+  // Optional XCD banding (workgroup b runs on XCD b % 8): one contiguous image band per XCD.  Off by
+  // default -- it loses to the round-robin order, see se_hip_raycast().
+  const int nwg = gridDim.x, per = (nwg + 7) >> 3;
+  int vwg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (((nwg & 7) != 0) || !a.xcd_swizzle) vwg = blockIdx.x;
+  const int tile = vwg * (SE_WG / 64) + (threadIdx.x >> 6);
   const int tiles_x = (a.W + 7) >> 3;
   const int px = ((tile % tiles_x) << 3) + (lane & 7);
   const int py = a.row_begin + ((tile / tiles_x) << 3) + (lane >> 3);
@@ -610,8 +696,9 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
   if (px < a.W && py < a.row_end) {
     const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
     const f3 org = {a.org[0], a.org[1], a.org[2]};
-    float tfar;
-    const float t_min = se_first_leaf(m, a, org, dir, &tfar, s_par, s_tmax);
+    const RaySpan span = se_first_leaf(m, a, org, dir, s_occ, s_par, s_tmax);
+    const float t_min = span.tcmin, tfar = span.tmax;
+    if (STATS) tk2 = __builtin_amdgcn_s_memtime();
     float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
     BlkCache c = {-1, -1, -1, 0u};
     if (t_min > 0.f) {
@@ -622,31 +709,60 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
           float t = tnear;
           float stepsize = a.largestep;
           f3 position = f3_add(org, f3_scale_r(dir, t));
-          float f_t = se_interp(m, f3_scale(a.inv_voxel, position), c);
+          float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
           if (STATS) ++n_interp;
           float f_tt = 0;
           if (f_t > 0) {
-            for (int guard = 0; t < tfar && guard < 65536; t += stepsize, ++guard) {
-              if (STATS) ++n_get;
-              // VolumeTemplate::get -> get_fine (volume_template.hpp:77-83)
-              const int ix = cvt_i32(a.inv_voxel * position.x), iy = cvt_i32(a.inv_voxel * position.y), iz = cvt_i32(a.inv_voxel * position.z);
-              const uint32_t e = se_block_of(m, ix, iy, iz, c);
-              float dx = m.init_x, dy = m.init_y;
-              if (e) { const size_t vi = se_voxel_index(e, ix, iy, iz); dx = m.vx[vi]; dy = m.vy[vi]; }
-              if (dy == 0) {
-                stepsize = a.largestep;
-                position = f3_add(position, f3_scale(stepsize, dir));
-                continue;
+            // The march is a chain of dependent memory round trips (sample -> step size -> next
+            // position).  Most steps repeat the previous step size (largestep through unobserved
+            // space, mu through observed free space where tsdf == 1), so SE_SPEC samples at
+            // position + k * S * dir are fetched in one round trip and consumed in order for as long
+            // as the step actually taken equals the predicted S bit for bit -- the positions are
+            // formed by the same float additions the sequential loop performs.
+            float S = a.largestep;
+            bool done = false;
+            for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+              f3 q[SE_SPEC];
+              uint32_t qe[SE_SPEC];
+              float qx[SE_SPEC], qy[SE_SPEC];
+              int qi[SE_SPEC][3];
+              q[0] = position;
+#pragma unroll
+              for (int i = 1; i < SE_SPEC; ++i) q[i] = f3_add(q[i - 1], f3_scale(S, dir));
+#pragma unroll
+              for (int i = 0; i < SE_SPEC; ++i) {
+                // VolumeTemplate::get -> get_fine (volume_template.hpp:77-83)
+                qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
+                qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
               }
-              f_tt = dx;
-              if ((double)f_tt <= 0.1 && f_tt >= -0.5f) {
-                f_tt = se_interp(m, f3_scale(a.inv_voxel, position), c);
-                if (STATS) ++n_interp;
+#pragma unroll
+              for (int i = 0; i < SE_SPEC; ++i) {
+                const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
+                qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
               }
-              if (f_tt < 0) break;
-              stepsize = fmaxf(f_tt * a.mu, a.step);
-              position = f3_add(position, f3_scale(stepsize, dir));
-              f_t = f_tt;
+#pragma unroll
+              for (int i = 0; i < SE_SPEC; ++i) {
+                if (!(t < tfar)) { done = true; break; }
+                if (STATS) ++n_get;
+                const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
+                if (dy == 0) {
+                  stepsize = a.largestep;
+                  position = f3_add(position, f3_scale(stepsize, dir));
+                } else {
+                  f_tt = dx;
+                  if ((double)f_tt <= 0.1 && f_tt >= -0.5f) {
+                    c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
+                    f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
+                    if (STATS) ++n_interp;
+                  }
+                  if (f_tt < 0) { done = true; break; }
+                  stepsize = fmaxf(f_tt * a.mu, a.step);
+                  position = f3_add(position, f3_scale(stepsize, dir));
+                  f_t = f_tt;
+                }
+                t += stepsize;
+                if (stepsize != S) { S = stepsize; break; }
+              }
             }
             if (f_tt < 0) {
               t = t + stepsize * f_tt / (f_t - f_tt);
@@ -660,23 +776,50 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
         if (tnear < tfar) {
           float t = tnear;
           const float stepsize = a.step;
-          float f_t = se_interp(m, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
+          float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
           if (STATS) ++n_interp;
           float f_tt = 0;
           if (f_t <= 0.f) {
-            for (int guard = 0; t < tfar && guard < 65536; t += stepsize, ++guard) {
-              const f3 pos = f3_add(org, f3_scale_r(dir, t));
-              if (STATS) ++n_get;
-              const int ix = cvt_i32(a.inv_voxel * pos.x), iy = cvt_i32(a.inv_voxel * pos.y), iz = cvt_i32(a.inv_voxel * pos.z);
-              const uint32_t e = se_block_of(m, ix, iy, iz, c);
-              float dx = m.init_x, dy = m.init_y;
-              if (e) { const size_t vi = se_voxel_index(e, ix, iy, iz); dx = m.vx[vi]; dy = m.vy[vi]; }
-              if (dx > -100.f && dy > 0.f) {
-                f_tt = se_interp(m, f3_scale(a.inv_voxel, pos), c);
-                if (STATS) ++n_interp;
+            // fixed step: every sample position origin + dir * t_k with t_k+1 = t_k + step is known in
+            // advance, so SE_SPEC_OF gets share one memory round trip
+            bool done = false;
+            for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+              float tt[SE_SPEC_OF];
+              f3 q[SE_SPEC_OF];
+              uint32_t qe[SE_SPEC_OF];
+              float qx[SE_SPEC_OF], qy[SE_SPEC_OF];
+              int qi[SE_SPEC_OF][3];
+              tt[0] = t;
+#pragma unroll
+              for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
+#pragma unroll
+              for (int i = 0; i < SE_SPEC_OF; ++i) {
+                q[i] = f3_add(org, f3_scale_r(dir, tt[i]));
+                qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
+                qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
               }
-              if (f_tt > 0.f) break;
-              f_t = f_tt;
+#pragma unroll
+              for (int i = 0; i < SE_SPEC_OF; ++i) {
+                const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
+                qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
+              }
+              bool stop = false;
+#pragma unroll
+              for (int i = 0; i < SE_SPEC_OF; ++i) {
+                if (stop) continue;
+                t = tt[i];
+                if (!(t < tfar)) { done = true; stop = true; continue; }
+                if (STATS) ++n_get;
+                const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
+                if (dx > -100.f && dy > 0.f) {
+                  c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
+                  f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
+                  if (STATS) ++n_interp;
+                }
+                if (f_tt > 0.f) { done = true; stop = true; continue; }
+                f_t = f_tt;
+              }
+              if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
             }
             if (f_tt > 0.f) {
               t = t - stepsize * (f_tt - 0.f) / (f_tt - f_t);
@@ -687,12 +830,13 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
         }
       }
     }
+    if (STATS) tk3 = __builtin_amdgcn_s_memtime();
     float* v = vertex + 3 * (size_t)(px + py * a.W);
     float* n = normal + 3 * (size_t)(px + py * a.W);
     if ((double)hw > 0.0) {
       if (STATS) { ++n_hit; ++n_grad; }
       v[0] = hx; v[1] = hy; v[2] = hz;
-      const f3 g = se_grad(m, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
+      const f3 g = se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
       const f3 surfNorm = f3_scale(a.grad_scale, g);
       if (sqrtf(f3_sqnorm(surfNorm)) == 0) {
         n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;  // INVALID (commons.h:71)
@@ -710,9 +854,26 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
     se_stat_add<true>(m, S_INTERPS, n_interp);
     se_stat_add<true>(m, S_GRADS, n_grad);
     se_stat_add<true>(m, S_HITS, n_hit);
+    // per-wave phase clocks (shader cycles): LDS staging, first-leaf search, march, gradient + store
+    const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      atomicAdd(&m.stats[S_T_STAGE], tk1 - tk0);
+      atomicAdd(&m.stats[S_T_ITER], tk2 - tk1);
+      atomicAdd(&m.stats[S_T_MARCH], tk3 - tk2);
+      atomicAdd(&m.stats[S_T_GRAD], tk4 - tk3);
+      atomicMax(&m.stats[S_T_WAVEMAX], tk4 - tk0);
+      atomicMax(&m.stats[13], tk2 - tk1);
+      atomicMax(&m.stats[14], tk3 - tk2);
+      atomicMax(&m.stats[15], tk4 - tk3);
+    }
   }
 }
 
+// map read-back: packs the bricks named by slots[] (already in the caller's order) contiguously
+__global__ __launch_bounds__(SE_WG) void k_gather_bricks(const float* __restrict__ plane, const uint32_t* __restrict__ slots, size_t n, float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 512; i += (size_t)gridDim.x * SE_WG)
+    out[i] = plane[(size_t)slots[i >> 9] * 512 + (i & 511)];
+}
 // pool initialisation: every voxel / node value starts at voxel_traits<T>::initValue()
 __global__ void k_fill(float* __restrict__ p, float v, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;

@@ -18,7 +18,8 @@ from . import build as _build
 
 SDF, OFUSION = 0, 1
 KERNELS = ("alloc_scan", "alloc_commit", "integrate", "raycast")
-STAT_NAMES = ("probes", "new_keys", "swept", "nodes", "gets", "interps", "grads", "hits")
+STAT_NAMES = ("probes", "new_keys", "swept", "nodes", "gets", "interps", "grads", "hits",
+              "clk_iter", "clk_march", "clk_grad", "clk_wave_max", "clk_stage", "r13", "r14", "r15")
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _LIB = None
@@ -225,6 +226,6 @@ class DenseSLAMPipeline:
         self._check(self.lib.se_hip_enable_stats(self._h, int(on)))
 
     def stats(self, reset: bool = False) -> dict:
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self.lib.se_hip_get_stats(self._h, out, int(reset)))
         return dict(zip(STAT_NAMES, (int(v) for v in out)))
