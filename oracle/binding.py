@@ -84,6 +84,11 @@ def _declare(lib):
         "so_pipe_count_stats": (None, [vp, i32]),
         "so_pipe_integrate": (i32, [vp, c_f32p, c_f32p, c_f32p, C.c_uint, f32, C.c_uint]),
         "so_pipe_raycast": (i32, [vp, c_f32p, c_f32p, f32, C.c_uint, c_f32p, c_f32p]),
+        "so_pipe_scan": (C.c_uint, [vp, c_f32p, c_f32p, c_f32p, f32, C.c_uint]),
+        "so_pipe_get_keys": (None, [vp, c_u64p, C.c_uint]),
+        "so_pipe_allocate_keys": (None, [vp, c_u64p, C.c_uint]),
+        "so_pipe_activate": (i32, [vp, c_i32p, i32]),
+        "so_pipe_sweep": (None, [vp, c_f32p, c_f32p, c_f32p, f32, C.c_uint]),
         "so_pipe_counts": (None, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "so_pipe_get_blocks": (None, [vp, c_i32p, c_f32p, c_f32p, c_u8p]),
         "so_pipe_get_nodes": (None, [vp, c_u64p, c_u32p, c_f32p, c_f32p]),
@@ -142,6 +147,29 @@ class OraclePipeline:
         from supereight_amd.synthetic import to_colmajor
         d = np.ascontiguousarray(depth, dtype=np.float32).reshape(-1)
         return bool(self.lib.so_pipe_integrate(self.h, d, to_colmajor(pose), np.asarray(k, np.float32), rate, mu, frame))
+
+    # staged variants (multi-rank protocol tests)
+    def scan_keys(self, depth, pose, k, mu, frame) -> np.ndarray:
+        from supereight_amd.synthetic import to_colmajor
+        d = np.ascontiguousarray(depth, dtype=np.float32).reshape(-1)
+        n = self.lib.so_pipe_scan(self.h, d, to_colmajor(pose), np.asarray(k, np.float32), mu, frame)
+        keys = np.zeros(n, np.uint64)
+        if n:
+            self.lib.so_pipe_get_keys(self.h, keys, n)
+        return keys
+
+    def allocate_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self.lib.so_pipe_allocate_keys(self.h, keys, len(keys))
+
+    def activate(self, coords) -> int:
+        c = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 3)
+        return self.lib.so_pipe_activate(self.h, c.reshape(-1), len(c)) if len(c) else 0
+
+    def sweep(self, depth, pose, k, mu, frame):
+        from supereight_amd.synthetic import to_colmajor
+        d = np.ascontiguousarray(depth, dtype=np.float32).reshape(-1)
+        self.lib.so_pipe_sweep(self.h, d, to_colmajor(pose), np.asarray(k, np.float32), mu, frame)
 
     def raycast(self, pose, k, mu, frame):
         from supereight_amd.synthetic import to_colmajor

@@ -154,6 +154,15 @@ void make_logodds(const std::vector<float>& lut, std::vector<float>& tab) {
     }
 }
 
+int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlists, long long stride_words) {
+  HIP_TRY(hipMemsetAsync(p->chain, 0xFF, 4 * sizeof(unsigned long long), p->stream));
+  ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
+  for (int j = 0; j < 3; ++j)
+    hipLaunchKernelGGL(k_min_key, dim3(64), dim3(SE_WG), 0, p->stream, lists, nlists, stride_words, p->chain + j, p->chain + (j ? j - 1 : 0), j ? 1 : 0);
+  hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(64), 0, p->stream, p->map, p->chain);
+  return SE_HIP_OK;
+}
+
 int check(se_hip_pipeline* p) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
   hipError_t e = hipSetDevice(p->device);
@@ -373,6 +382,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   a.inv_voxel = sdf ? 1 / voxelsize : 1.f / voxelsize;
   a.num_steps = (int)std::ceil(a.band * a.inv_voxel);
   a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+  a.sharded = (p->row_begin != 0 || p->row_end != p->cfg.height) ? 1 : 0;
   // step_to_depth (bfusion/alloc_impl.hpp:48-51) for the three step sizes of compute_stepsize
   auto s2d = [&](float step) { return (int)(floorf(log2f(voxelsize / step)) + m.max_level); };
   a.depth_fine = s2d(voxelsize); a.depth_mid = s2d(10.f * voxelsize); a.depth_coarse = s2d(30.f * voxelsize);
@@ -389,13 +399,10 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
       else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, p->stream, m, p->depth, a);
     }
   }
-  if (!sdf) {
-    // keys[0] quirk of unique_multiscale (see k_zero_chain)
-    HIP_TRY(hipMemsetAsync(p->chain, 0xFF, 4 * sizeof(unsigned long long), p->stream));
-    ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
-    for (int j = 0; j < 3; ++j)
-      hipLaunchKernelGGL(k_min_key, dim3(64), dim3(SE_WG), 0, p->stream, m, p->chain + j, p->chain + (j ? j - 1 : 0), j ? 1 : 0);
-    hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(64), 0, p->stream, m, p->chain);
+  // keys[0] quirk of unique_multiscale (see k_zero_chain): needs the frame's complete key list, so a
+  // row-sharded replica defers it to se_hip_alloc_commit (which sees every rank's list)
+  if (!sdf && !a.sharded) {
+    if (int r = run_zero_chain(p, m.newkeys, 1, (long long)m.cap_keys + 1)) return r;
   }
   HIP_TRY(hipGetLastError());
   return 1;
@@ -419,8 +426,12 @@ int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
-  ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
-  hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, (const unsigned long long*)device_lists, nlists, (long long)stride_words);
+  {
+    ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
+    hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, (const unsigned long long*)device_lists, nlists, (long long)stride_words);
+  }
+  if (p->cfg.field_type == SE_HIP_FIELD_OFUSION)
+    if (int r = run_zero_chain(p, (const unsigned long long*)device_lists, nlists, (long long)stride_words)) return r;
   HIP_TRY(hipGetLastError());
   return SE_HIP_OK;
 }

@@ -56,10 +56,17 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
   return true;
 }
 
-__device__ __forceinline__ void se_append_key(const DevMap& m, int level, int x, int y, int z) {
+#define SE_KEY_ACTIVATE (1ull << 63)  // list entry = "set VoxelBlock::active_ of this existing block"
+__device__ __forceinline__ void se_append_key(const DevMap& m, int level, int x, int y, int z, unsigned long long flag = 0ull) {
   const unsigned long long idx = atomicAdd(&m.newkeys[0], 1ull);
-  if (idx < m.cap_keys) m.newkeys[1 + idx] = se_make_key(x, y, z, level, m.max_level);
+  if (idx < m.cap_keys) m.newkeys[1 + idx] = se_make_key(x, y, z, level, m.max_level) | flag;
   else m.ctr[C_OVERFLOW] = 2u;
+}
+// n->active(true) of the allocation scans.  A row-sharded replica only sees its own rays, so a block
+// it switches from inactive to active is also reported to the peers (which cannot see that ray).
+__device__ __forceinline__ void se_mark_active(const DevMap& m, uint32_t slot, bool sharded, int bx, int by, int bz) {
+  if (sharded && m.bactive[slot] == 0) se_append_key(m, m.leaf_level, bx, by, bz, SE_KEY_ACTIVATE);
+  m.bactive[slot] = 1;
 }
 
 template <bool STATS> __device__ __forceinline__ void se_stat_add(const DevMap& m, int which, unsigned long long v) {
@@ -79,6 +86,7 @@ struct AllocArgs {
   int num_steps;    // SDF: ceil(band * inv_voxel)
   int W, H, row_begin, row_end;
   int depth_fine, depth_mid, depth_coarse;  // OFusion: step_to_depth() of the three step sizes
+  int sharded;      // this replica scans only part of the image: report re-activated blocks to the peers
 };
 
 // ------------------------------------------------------------------------------------------
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_scan_sdf(DevMap m, const float*
             if (e == 0u) {
               if (se_insert_octant(m, m.leaf_level, bx, by, bz)) { se_append_key(m, m.leaf_level, bx, by, bz); ++newk; }
             } else if (e != SE_PENDING) {
-              m.bactive[e - 1u] = 1;  // n->active(true), alloc_impl.hpp:109
+              se_mark_active(m, e - 1u, a.sharded != 0, bx, by, bz);  // n->active(true), alloc_impl.hpp:109
             }
           }
         }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_scan_ofusion(DevMap m, const fl
           if (e == 0u) {
             if (se_insert_octant(m, lvl, ox, oy, oz)) { se_append_key(m, lvl, ox, oy, oz); ++newk; }
           } else if (tree_depth >= m.leaf_level && e != SE_PENDING) {
-            m.bactive[e - 1u] = 1;
+            se_mark_active(m, e - 1u, a.sharded != 0, ox, oy, oz);
           }
         }
         // compute_stepsize / step_to_depth (alloc_impl.hpp:37-51); the three depths are
@@ -192,29 +200,43 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_commit(DevMap m, const unsigned
   unsigned long long n = list[0];
   if (n > (unsigned long long)(stride_words - 1)) n = (unsigned long long)(stride_words - 1);
   for (unsigned long long i = blockIdx.x * (unsigned long long)SE_WG + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * SE_WG) {
-    const unsigned long long key = list[1 + i];
+    const unsigned long long raw = list[1 + i];
+    const bool activate = (raw & SE_KEY_ACTIVATE) != 0ull;
+    const unsigned long long key = raw & ~SE_KEY_ACTIVATE;
     const int level = (int)(key & 0x1FFull);
     if (level < 1 || level > m.leaf_level) continue;
     const unsigned long long code = key & ~0x1FFull;
     const int sh = m.max_level - level;
     const int x = (int)(se_compact21(code) >> sh), y = (int)(se_compact21(code >> 1) >> sh), z = (int)(se_compact21(code >> 2) >> sh);
     if ((unsigned)x >= (1u << level) || (unsigned)y >= (1u << level) || (unsigned)z >= (1u << level)) continue;
-    se_insert_octant(m, level, x, y, z);
+    if (activate) {
+      if (level != m.leaf_level) continue;
+      const uint32_t e = m.tab[leaf_index(m, x, y, z)];
+      if (e != 0u && e != SE_PENDING) m.bactive[e - 1u] = 1;
+    } else {
+      se_insert_octant(m, level, x, y, z);
+    }
   }
 }
 
 // unique_multiscale keeps keys[0] whatever its level (se_core/include/se/algorithms/unique.hpp:64-79):
 // when the smallest key of a frame's list (after filter_ancestors) is a coarse octant, the
 // reference walks it down to the leaves along child 0.  k_min_key finds the smallest key greater
-// than `lower` (3 passes resolve the ancestor chain), k_zero_chain inserts that chain.
-__global__ __launch_bounds__(SE_WG) void k_min_key(DevMap m, unsigned long long* out, const unsigned long long* lower_ptr, int has_lower) {
-  unsigned long long n = m.newkeys[0];
-  if (n > m.cap_keys) n = m.cap_keys;
+// than `lower` over the frame's key list(s) (3 passes resolve the ancestor chain), k_zero_chain
+// inserts that chain.
+__global__ __launch_bounds__(SE_WG) void k_min_key(const unsigned long long* __restrict__ lists, int nlists, long long stride_words,
+                                                    unsigned long long* out, const unsigned long long* lower_ptr, int has_lower) {
   const unsigned long long lower = has_lower ? *lower_ptr : 0ull;
   unsigned long long best = ~0ull;
-  for (unsigned long long i = blockIdx.x * (unsigned long long)SE_WG + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * SE_WG) {
-    const unsigned long long k = m.newkeys[1 + i];
-    if ((!has_lower || k > lower) && k < best) best = k;
+  for (int li = 0; li < nlists; ++li) {
+    const unsigned long long* list = lists + (long long)li * stride_words;
+    unsigned long long n = list[0];
+    if (n > (unsigned long long)(stride_words - 1)) n = (unsigned long long)(stride_words - 1);
+    for (unsigned long long i = blockIdx.x * (unsigned long long)SE_WG + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * SE_WG) {
+      const unsigned long long k = list[1 + i];
+      if (k & SE_KEY_ACTIVATE) continue;
+      if ((!has_lower || k > lower) && k < best) best = k;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_down(best, o); if (v < best) best = v; }
   if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(out, best);

@@ -1,0 +1,99 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads, exports every entry point that
+include/se_hip.h declares, fails loudly without a GPU, and the host-side helpers behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "se_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(se_hip_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from supereight_amd import build
+    lib = C.CDLL(build.build())
+    names = declared_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"libse_hip.so does not export {n}"
+
+
+def test_binding_covers_the_header():
+    from supereight_amd.pipeline import EXPORTS
+    assert sorted(EXPORTS) == declared_functions()
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must fail loudly (no silent CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from supereight_amd.pipeline import DenseSLAMPipeline, SeHipError
+    with pytest.raises(SeHipError, match="no HIP device|no CPU path"):
+        DenseSLAMPipeline((64, 48), 128, 1.2)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "supereight_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle", text, flags=re.M), f"{f} uses the oracle"
+
+
+def test_create_argument_validation():
+    from supereight_amd.pipeline import _Config, load_library
+    lib = load_library()
+    h = C.c_void_p()
+    for bad in (dict(width=0), dict(volume_resolution=500), dict(volume_resolution=32), dict(volume_dimension=0.0),
+                dict(field_type=7)):
+        kw = dict(width=64, height=48, volume_resolution=128, volume_dimension=1.2, field_type=0, device=0,
+                  max_blocks=0, row_begin=0, row_end=0)
+        kw.update(bad)
+        cfg = _Config(**kw)
+        assert lib.se_hip_create(C.byref(cfg), C.byref(h)) == -1   # SE_HIP_E_INVALID, before any device call
+        assert lib.se_hip_last_error()
+    assert lib.se_hip_create(None, C.byref(h)) == -1
+
+
+def test_row_partition():
+    from supereight_amd.multi_gpu import row_partition
+    for H in (480, 960, 120, 8, 100):
+        for R in (1, 2, 3, 4, 8):
+            parts = row_partition(H, R)
+            assert parts[0][0] == 0 and parts[-1][1] == H
+            for (a, b), (c, d) in zip(parts, parts[1:]):
+                assert b == c and a <= b
+            for a, b in parts[:-1]:
+                assert a % 8 == 0 and b % 8 == 0
+    sizes = [b - a for a, b in row_partition(480, 8)]
+    assert max(sizes) - min(sizes) <= 8
+
+
+def test_synthetic_stream_properties():
+    from supereight_amd.synthetic import HoleStream, SyntheticStream, intrinsics, pose, surface_distance, to_colmajor
+    k = intrinsics(640)
+    assert np.allclose(k, [481.2, 480, 320, 240])
+    s = SyntheticStream(640, 480, 4.8)
+    d0 = s.depth(0)
+    assert d0.shape == (480, 640) and d0.dtype == np.float32
+    holes = (d0 == 0).sum()
+    assert holes == 6125                       # libstdc++ mt19937(54321) + uniform_real<float> < 0.02 (checked against g++)
+    assert 1.0 < d0[d0 > 0].min() and d0.max() < 4.7
+    with pytest.raises(ValueError):
+        s.depth(5)
+    P = pose(10, 4.8)
+    assert np.allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-6)
+    assert np.allclose(to_colmajor(P).reshape(4, 4).T, P)
+    u = HoleStream().uniform(5)
+    assert np.allclose(u, [0.911640763, 0.509720981, 0.623824835, 0.183354408, 0.791803837], atol=1e-8)
+    pts = np.array([[0.05 * 4.8, 1.0, 1.0], [2.4, 2.4, 0.62 * 4.8 - 0.08 * 4.8]])
+    assert np.allclose(surface_distance(pts, 4.8), 0, atol=1e-6)

@@ -1,0 +1,64 @@
+"""The N > 1 path on ONE GPU: R row-sharded replicas live in one process on the same device and
+the all-gather is emulated by concatenating their key-list buffers.  Every replica must end up with
+the map of the unsharded pipeline, and the stitched row tiles of their raycasts must equal its
+vertex / normal images -- bit for bit."""
+import numpy as np
+import pytest
+
+from oracle.binding import OFUSION, SDF
+from supereight_amd.multi_gpu import BIG_FRAMES, row_partition
+from supereight_amd.pipeline import DenseSLAMPipeline
+from supereight_amd.synthetic import SyntheticStream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("field,mu,R", [(SDF, 0.1, 2), (SDF, 0.1, 4), (OFUSION, 0.02, 2)], ids=["sdf-2", "sdf-4", "ofusion-2"])
+def test_sharded_replicas_equal_single(field, mu, R):
+    import torch
+    W, H, N, dim, frames = 160, 120, 256, 2.4, 6
+    dev = torch.device("cuda", 0)
+    stream = SyntheticStream(W, H, dim)
+    single = DenseSLAMPipeline((W, H), N, dim, field_type=field)
+    parts = row_partition(H, R)
+    reps = [DenseSLAMPipeline((W, H), N, dim, field_type=field, rows=parts[r]) for r in range(R)]
+    words = 1 << 15
+    send = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(R)]
+    for r in range(R):
+        reps[r].set_new_keys_buffer(send[r].data_ptr(), words, keepalive=send[r])
+    for f in range(frames):
+        depth, pose = stream.depth(f), stream.pose(f)
+        single.set_depth(depth); single.setPose(pose)
+        single.integration(stream.k, 1, mu, f)
+        single.raycasting(stream.k, mu, f)
+        for p in reps:
+            p.set_depth(depth); p.setPose(pose)
+            assert p.alloc_scan(stream.k, 1, mu, f)
+        for p in reps:
+            p.sync()
+        recv = torch.cat(send)                       # what all_gather_into_tensor delivers on every rank
+        torch.cuda.synchronize()                     # (the replicas run on their own streams)
+        for p in reps:
+            p.alloc_commit(recv.data_ptr(), R, words)
+            p.integrate_sweep(stream.k, 1, mu, f)
+            p.raycasting(stream.k, mu, f)
+        for p in reps:
+            p.sync()
+    c, x, y, a = single.blocks()
+    code, side, nx, ny = single.nodes()
+    v, n = single.vertex_normal()
+    assert len(c) > 500 and (n[..., 0] != -2).sum() > 5000
+    vs, ns = np.zeros_like(v), np.zeros_like(n)
+    for r, p in enumerate(reps):
+        rc, rx, ry, ra = p.blocks()
+        assert rc.shape == c.shape and (rc == c).all()
+        assert (rx.view(np.uint32) == x.view(np.uint32)).all() and (ry.view(np.uint32) == y.view(np.uint32)).all()
+        assert (ra == a).all()
+        rcode, rside, rnx, rny = p.nodes()
+        assert (rcode == code).all() and (rnx.view(np.uint32) == nx.view(np.uint32)).all()
+        rv, rn = p.vertex_normal()
+        b, e = parts[r]
+        vs[b:e], ns[b:e] = rv[b:e], rn[b:e]
+        p.close()
+    assert (vs.view(np.uint32) == v.view(np.uint32)).all() and (ns.view(np.uint32) == n.view(np.uint32)).all()
+    single.close()
