@@ -40,6 +40,7 @@ struct DevMap {
   uint32_t* occ;                  // occupancy bit pyramid: level l has 8^l bits in Morton order at word woff[l]
   uint32_t woff[SE_MAX_LEVELS + 1];
   int size, max_level, leaf_level;
+  int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
   uint32_t leaf_off;              // = off[leaf_level]; kept separately so that hot kernels never index off[] dynamically
   float dim;
@@ -138,6 +139,7 @@ __device__ __forceinline__ uint32_t morton30(int x, int y, int z) {
 // DevMap arrays with a vector index would spill them to scratch).
 __host__ __device__ __forceinline__ uint32_t occ_woff(int l) { return l >= 3 ? 1u << (3 * l - 7) : (uint32_t)(l - 1); }
 __device__ __forceinline__ void occ_set(const DevMap& m, int l, int x, int y, int z) {
+  if (m.defer_occ) return;
   const uint32_t code = morton30(x, y, z);
   atomicOr(&m.occ[m.woff[l] + (code >> 5)], 1u << (code & 31u));
 }

@@ -63,6 +63,14 @@ struct se_hip_pipeline {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // side stream: the allocation scan (and the depth upload feeding it) of frame f+1 runs here,
+  // concurrently with the raycast of frame f on `stream` (dense, unsharded replicas only)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_sweep = nullptr, ev_scan = nullptr;
+  bool overlap = false;
+  bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
+  bool upload_on_side = false; // the current depth image was uploaded on `side`
+  bool occ_commit_due = false; // the next sweep kernel must publish the scan's occupancy bits
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
@@ -87,7 +95,7 @@ struct se_hip_pipeline {
   double ms_sum[SE_HIP_K_COUNT] = {0};
   int64_t launches[SE_HIP_K_COUNT] = {0};
   int row_begin = 0, row_end = 0;
-  int integ_grid = 2048;  // workgroups of the integration sweep (4 waves each)
+  int integ_grid = 0;  // > 0: fixed number of workgroups for the integration sweep (tuning knob)
 };
 
 namespace {
@@ -101,16 +109,17 @@ hipEvent_t get_event(se_hip_pipeline* p) {
   return e;
 }
 struct ScopedTimer {
-  se_hip_pipeline* p; int k; hipEvent_t a{}, b{};
-  ScopedTimer(se_hip_pipeline* p_, int k_) : p(p_), k(k_) {
-    if (p->timing) { a = get_event(p); b = get_event(p); hipEventRecord(a, p->stream); }
+  se_hip_pipeline* p; int k; hipStream_t s; hipEvent_t a{}, b{};
+  ScopedTimer(se_hip_pipeline* p_, int k_, hipStream_t s_ = nullptr) : p(p_), k(k_), s(s_ ? s_ : p_->stream) {
+    if (p->timing) { a = get_event(p); b = get_event(p); hipEventRecord(a, s); }
   }
   ~ScopedTimer() {
-    if (p->timing) { hipEventRecord(b, p->stream); p->pending.push_back({k, a, b}); }
+    if (p->timing) { hipEventRecord(b, s); p->pending.push_back({k, a, b}); }
   }
 };
 void drain_timings(se_hip_pipeline* p) {
   if (p->pending.empty()) return;
+  if (p->side) hipStreamSynchronize(p->side);
   hipStreamSynchronize(p->stream);
   for (auto& t : p->pending) {
     float ms = 0.f;
@@ -163,6 +172,36 @@ int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlis
   return SE_HIP_OK;
 }
 
+// Overlap mode: depth uploads go to the side stream, behind the previous sweep (the last reader of
+// the depth buffer) and in front of the scan that consumes them.
+hipStream_t upload_stream(se_hip_pipeline* p) {
+  if (!p->overlap) return p->stream;
+  hipStreamWaitEvent(p->side, p->ev_sweep, 0);
+  return p->side;
+}
+
+// Makes the main stream see a scan that ran on the side stream: wait for it, then publish the
+// occupancy bits of what it inserted (the scan left occ[] alone because the previous frame's raycast
+// may still have been walking it) and apply OFusion's keys[0] quirk.
+int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
+  if (!p->scan_pending) {
+    if (p->upload_on_side) { hipEventRecord(p->ev_scan, p->side); hipStreamWaitEvent(p->stream, p->ev_scan, 0); p->upload_on_side = false; }
+    return SE_HIP_OK;
+  }
+  p->scan_pending = false;
+  p->upload_on_side = false;
+  HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0));
+  if (fold_into_sweep) {
+    p->occ_commit_due = true;   // the sweep kernel launched next publishes the bits itself
+  } else {
+    ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
+    hipLaunchKernelGGL(k_occ_commit, dim3(64), dim3(SE_WG), 0, p->stream, p->map);
+  }
+  if (p->cfg.field_type == SE_HIP_FIELD_OFUSION)
+    if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r;
+  return SE_HIP_OK;
+}
+
 int check(se_hip_pipeline* p) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
   hipError_t e = hipSetDevice(p->device);
@@ -204,6 +243,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->row_end = (cfg->row_end > cfg->row_begin) ? cfg->row_end : cfg->height;
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
   p->max_level = ilog2(N);
   p->leaf_level = p->max_level - 3;
   DevMap& m = p->map;
@@ -241,6 +281,12 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
   if (e != hipSuccess) return bail(e, "hipStreamCreate");
   p->own_stream = true;
+  e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+  if (e != hipSuccess) return bail(e, "hipStreamCreate");
+  hipEventCreateWithFlags(&p->ev_sweep, hipEventDisableTiming);
+  hipEventCreateWithFlags(&p->ev_scan, hipEventDisableTiming);
+  const bool sharded = (p->row_begin != 0 || p->row_end != cfg->height);
+  p->overlap = dense && !sharded && !std::getenv("SE_HIP_NO_OVERLAP");
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
   ALLOC(m.vx, slots * 512 * sizeof(float));
@@ -300,6 +346,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
 int se_hip_destroy(se_hip_pipeline* p) {
   if (!p) return SE_HIP_OK;
   hipSetDevice(p->device);
+  if (p->side) hipStreamSynchronize(p->side);
   if (p->stream) hipStreamSynchronize(p->stream);
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
@@ -308,6 +355,9 @@ int se_hip_destroy(se_hip_pipeline* p) {
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain};
   for (void* q : ptrs) if (q) hipFree(q);
   if (p->ctr_host) hipHostFree(p->ctr_host);
+  if (p->side) hipStreamDestroy(p->side);
+  if (p->ev_sweep) hipEventDestroy(p->ev_sweep);
+  if (p->ev_scan) hipEventDestroy(p->ev_scan);
   if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
   delete p;
   return SE_HIP_OK;
@@ -315,6 +365,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
 
 int se_hip_sync(se_hip_pipeline* p) {
   if (int r = check(p)) return r;
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return SE_HIP_OK;
 }
@@ -332,7 +383,9 @@ int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
 int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m) {
   if (int r = check(p)) return r;
   if (!host_depth_m) return fail(SE_HIP_E_INVALID, "null depth");
-  HIP_TRY(hipMemcpyAsync(p->depth_own, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), hipMemcpyHostToDevice, p->stream));
+  hipStream_t s = upload_stream(p);
+  HIP_TRY(hipMemcpyAsync(p->depth_own, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), hipMemcpyHostToDevice, s));
+  if (!p->overlap) {} else p->upload_on_side = true;
   p->depth = p->depth_own;
   return SE_HIP_OK;
 }
@@ -350,8 +403,10 @@ int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t 
     HIP_TRY(hipMalloc((void**)&p->depth_mm, n * sizeof(unsigned short)));
     p->depth_mm_cap = n;
   }
-  HIP_TRY(hipMemcpyAsync(p->depth_mm, host_mm, n * sizeof(unsigned short), hipMemcpyHostToDevice, p->stream));
-  hipLaunchKernelGGL(k_mm2meters, dim3((W + 255) / 256, H), dim3(256), 0, p->stream, p->depth_own, W, H, p->depth_mm, in_w, in_w / W);
+  hipStream_t s = upload_stream(p);
+  HIP_TRY(hipMemcpyAsync(p->depth_mm, host_mm, n * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_mm2meters, dim3((W + 255) / 256, H), dim3(256), 0, s, p->depth_own, W, H, p->depth_mm, in_w, in_w / W);
+  if (p->overlap) p->upload_on_side = true;
   HIP_TRY(hipGetLastError());
   p->depth = p->depth_own;
   return SE_HIP_OK;
@@ -386,18 +441,31 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   // step_to_depth (bfusion/alloc_impl.hpp:48-51) for the three step sizes of compute_stepsize
   auto s2d = [&](float step) { return (int)(floorf(log2f(voxelsize / step)) + m.max_level); };
   a.depth_fine = s2d(voxelsize); a.depth_mid = s2d(10.f * voxelsize); a.depth_coarse = s2d(30.f * voxelsize);
-  HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), p->stream));
+  // Overlap mode: the scan runs on the side stream as soon as the previous sweep is done, i.e.
+  // concurrently with the previous frame's raycast, and defers its occ[] updates (join_scan).
+  const bool ov = p->overlap;
+  hipStream_t s = ov ? p->side : p->stream;
+  DevMap ms = m;
+  ms.defer_occ = ov ? 1 : 0;
+  if (ov) HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0));
+  HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), s));
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
   const dim3 grid((npix + SE_WG - 1) / SE_WG), block(SE_WG);
   {
-    ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN);
+    ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
-      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_sdf<true>, grid, block, 0, p->stream, m, p->depth, a);
-      else hipLaunchKernelGGL(k_alloc_scan_sdf<false>, grid, block, 0, p->stream, m, p->depth, a);
+      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_sdf<true>, grid, block, 0, s, ms, p->depth, a);
+      else hipLaunchKernelGGL(k_alloc_scan_sdf<false>, grid, block, 0, s, ms, p->depth, a);
     } else {
-      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, p->stream, m, p->depth, a);
-      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, p->stream, m, p->depth, a);
+      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
+      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
     }
+  }
+  if (ov) {
+    HIP_TRY(hipEventRecord(p->ev_scan, p->side));
+    p->scan_pending = true;
+    HIP_TRY(hipGetLastError());
+    return 1;
   }
   // keys[0] quirk of unique_multiscale (see k_zero_chain): needs the frame's complete key list, so a
   // row-sharded replica defers it to se_hip_alloc_commit (which sees every rank's list)
@@ -410,6 +478,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
 
 int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* capacity_words) {
   if (int r = check(p)) return r;
+  if (int r = join_scan(p)) return r;
   if (device_list) *device_list = (uint64_t*)p->map.newkeys;
   if (capacity_words) *capacity_words = (int64_t)p->map.cap_keys + 1;
   return SE_HIP_OK;
@@ -426,6 +495,7 @@ int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (int r = join_scan(p)) return r;
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
     hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, (const unsigned long long*)device_lists, nlists, (long long)stride_words);
@@ -440,10 +510,13 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   if (int r = check(p)) return r;
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!stage_runs_integration(frame, rate)) return 0;
+  if (int r = join_scan(p, true)) return r;
   const DevMap& m = p->map;
   const M4 pose = from_colmajor(pose_cm);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   IntegArgs a{};
+  a.commit_occ = p->occ_commit_due ? 1 : 0;
+  p->occ_commit_due = false;
   // Sophus::SE3f(pose_).inverse() (DenseSLAMSystem.cpp:237): (R^T, R^T * (t * -1)) taken from the matrix
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) a.R[i * 3 + j] = pose.m[j][i];
@@ -469,9 +542,13 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   a.bspline = p->bspline; a.logodds = p->logodds;
   const dim3 block(SE_WG);
   {
-    // one launch: blocks (one wave each, grid-stride; the block count lives on the device) then nodes
+    // one launch: blocks (one wave each) then nodes.  The block count lives on the device; the grid is
+    // sized from the count read back asynchronously after the previous sweep (+ headroom), and the
+    // kernel's grid-stride loop covers whatever that estimate misses.
     ScopedTimer t(p, SE_HIP_K_INTEGRATE);
-    const dim3 grid(p->integ_grid);
+    const size_t est = (size_t)p->ctr_host[C_BLOCKS] + (size_t)p->ctr_host[C_BLOCKS] / 8 + 2048;
+    const size_t wgs = std::min<size_t>(std::max<size_t>((est + 3) / 4, 2048), 65536);
+    const dim3 grid(p->integ_grid > 0 ? (unsigned)p->integ_grid : (unsigned)wgs);
     if (sdf) {
       if (p->stats) hipLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, p->stream, m, p->depth, a);
       else hipLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, p->stream, m, p->depth, a);
@@ -480,6 +557,9 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
       else hipLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, p->stream, m, p->depth, a);
     }
   }
+  hipEventRecord(p->ev_sweep, p->stream);   // the next frame's scan / depth upload may start behind this point
+  // refresh the host copy of the counters for the next frame's launch geometry (no synchronisation)
+  hipMemcpyAsync(p->ctr_host, m.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
   HIP_TRY(hipGetLastError());
   return 1;
 }
@@ -495,6 +575,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (int r = check(p)) return r;
   if (!pose_cm || !k) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!(frame > 2)) return 0;  // DenseSLAMSystem.cpp:195
+  if (int r = join_scan(p)) return r;
   const DevMap& m = p->map;
   const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));  // DenseSLAMSystem.cpp:199
   RayArgs a{};
@@ -520,6 +601,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   // staged region = words [0, end of level cl)
   a.cache_words = cl > 0 ? (int)(occ_woff(cl) + std::max<size_t>(1, ((size_t)1 << (3 * cl)) / 32)) : 1;
   a.stack_depth = p->leaf_level;
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
   // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
   // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
   a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
@@ -565,6 +647,7 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** v, float** n) {
 
 // ----------------------------------------------------------------------------------- read-back
 static int fetch_counters(se_hip_pipeline* p) {
+  if (int r = join_scan(p)) return r;
   HIP_TRY(hipMemcpyAsync(p->ctr_host, p->map.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->ctr_host[C_OVERFLOW]) return fail(SE_HIP_E_CAPACITY, p->ctr_host[C_OVERFLOW] == 2 ? "new-key list overflow" : "block / node pool exhausted (raise max_blocks)");
@@ -683,6 +766,7 @@ int se_hip_enable_stats(se_hip_pipeline* p, int32_t on) {
 
 int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[16], int32_t reset) {
   if (int r = check(p)) return r;
+  if (int r = join_scan(p)) return r;
   unsigned long long h[S_COUNT];
   HIP_TRY(hipMemcpyAsync(h, p->map.stats, sizeof h, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
