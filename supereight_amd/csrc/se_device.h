@@ -133,11 +133,11 @@ __device__ __forceinline__ uint32_t tab_index_packed(const DevMap& m, int l, uin
 __device__ __forceinline__ uint32_t morton30(int x, int y, int z) {
   return (uint32_t)(se_expand21_d((unsigned long long)x) | (se_expand21_d((unsigned long long)y) << 1) | (se_expand21_d((unsigned long long)z) << 2));
 }
-// word offset of level l in occ[]: levels hold max(1, 8^l / 32) words; level l >= 3 starts at word
-// 2^(3l-7) (a quarter of its own size: the lower levels fit below it), levels 1 and 2 at words 0
-// and 1.  A closed form because l is a per-lane value in the ray traversal (indexing the by-value
+// word offset of level l in occ[]: levels hold max(1, 8^l / 32) words; level l starts at word
+// (8^l >> 7) + l (a quarter of its own size plus a few words: all lower levels fit below it).  A
+// branch-free closed form because l is a per-lane value in the ray traversal (indexing the by-value
 // DevMap arrays with a vector index would spill them to scratch).
-__host__ __device__ __forceinline__ uint32_t occ_woff(int l) { return l >= 3 ? 1u << (3 * l - 7) : (uint32_t)(l - 1); }
+__host__ __device__ __forceinline__ uint32_t occ_woff(int l) { return ((1u << (3 * l)) >> 7) + (uint32_t)l; }
 __device__ __forceinline__ void occ_set(const DevMap& m, int l, int x, int y, int z) {
   if (m.defer_occ) return;
   const uint32_t code = morton30(x, y, z);

@@ -659,24 +659,30 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
 
   f3 t_corner = {0.f, 0.f, 0.f};
   float tc_max = 0.f;
-  uint32_t gw_index = 0xFFFFFFFFu, gw_word = 0u;  // last occupancy word fetched from global memory
+  const int om = octant_mask ^ 7;
+  uint32_t gw_index = 0xFFFFFFFFu, gw_word = 0u;  // last occupancy word fetched from global memory (levels between cache and leaf)
+  uint32_t leaf_byte = 0u;                        // the 8 leaf-level sibling bits of the current parent
+  const uint8_t* occ_leaf_bytes = (const uint8_t*)(m.occ + occ_woff(m.leaf_level));
   for (int guard = 0; guard < 4096 && scale < 23; ++guard) {
     t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
     tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
-    const int cidx = idx ^ octant_mask ^ 7;
+    const int cidx = idx ^ om;
     const int clevel = 23 - scale;  // level of the child
     const uint32_t child = (parent << 3) | (uint32_t)cidx;
-    const uint32_t w = occ_woff(clevel) + (child >> 5);   // woff(1) == 0: LDS index == global index
-    // two separate loads (LDS / global): selecting between the pointers would force a flat load
-    uint32_t word = s_occ[min(w, (uint32_t)(a.cache_words - 1))];
+    const bool at_leaves = scale == a.min_scale;
+    // occupancy test: leaf level -> the sibling byte fetched when this parent was entered;
+    // staged levels -> LDS; levels in between (volumes > 512^3) -> global word, cached per word
+    const uint32_t w = occ_woff(clevel) + (child >> 5);
+    uint32_t word = s_occ[at_leaves || clevel > a.cache_levels ? 0u : w];
     asm volatile("" : "+v"(word));  // keep the LDS load an LDS load
-    if (clevel > a.cache_levels) {
-      // the 8 children of an octant share one byte: sibling tests reuse the word already fetched
+    uint32_t shift = child & 31u;
+    if (at_leaves) { word = leaf_byte; shift = (uint32_t)cidx; }
+    else if (clevel > a.cache_levels) {
       if (w != gw_index) { gw_index = w; gw_word = m.occ[w]; }
       word = gw_word;
     }
-    const bool exists = (word >> (child & 31u)) & 1u;
-    if (scale == a.min_scale && exists) break;  // leaf found: t_min is its entry distance
+    const bool exists = (word >> shift) & 1u;
+    if (at_leaves && exists) break;  // leaf found: t_min is its entry distance
     if (exists && t_min <= t_max) {
       // descend (ray_iterator.hpp:172-199)
       const float tv_max = fminf(t_max, tc_max);
@@ -685,23 +691,21 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
       if (tc_max < h) { s_par[(22 - scale) * SE_WG + tid] = parent; s_tmax[(22 - scale) * SE_WG + tid] = t_max; }
       h = tc_max;
       parent = child;
-      idx = 0;
       scale--;
+      if (scale == a.min_scale) leaf_byte = occ_leaf_bytes[child];  // issued now, first used next trip
       scale_exp2 = half;
-      idx ^= (t_center.x > t_min) ? 1 : 0;
-      idx ^= (t_center.y > t_min) ? 2 : 0;
-      idx ^= (t_center.z > t_min) ? 4 : 0;
-      pos.x += scale_exp2 * (float)((idx & 1) != 0);
-      pos.y += scale_exp2 * (float)((idx & 2) != 0);
-      pos.z += scale_exp2 * (float)((idx & 4) != 0);
+      idx = ((t_center.x > t_min) ? 1 : 0) | ((t_center.y > t_min) ? 2 : 0) | ((t_center.z > t_min) ? 4 : 0);
+      pos.x += (idx & 1) ? scale_exp2 : 0.f;
+      pos.y += (idx & 2) ? scale_exp2 : 0.f;
+      pos.z += (idx & 4) ? scale_exp2 : 0.f;
       t_max = tv_max;
       continue;
     }
     // advance_ray (ray_iterator.hpp:116-167)
-    const int step_mask = (t_corner.x <= tc_max) | ((t_corner.y <= tc_max) << 1) | ((t_corner.z <= tc_max) << 2);
-    pos.x -= scale_exp2 * (float)((step_mask & 1) != 0);
-    pos.y -= scale_exp2 * (float)((step_mask & 2) != 0);
-    pos.z -= scale_exp2 * (float)((step_mask & 4) != 0);
+    const int step_mask = (t_corner.x <= tc_max ? 1 : 0) | (t_corner.y <= tc_max ? 2 : 0) | (t_corner.z <= tc_max ? 4 : 0);
+    pos.x -= (step_mask & 1) ? scale_exp2 : 0.f;
+    pos.y -= (step_mask & 2) ? scale_exp2 : 0.f;
+    pos.z -= (step_mask & 4) ? scale_exp2 : 0.f;
     t_min = tc_max;
     idx ^= step_mask;
     if ((idx & step_mask) != 0) {

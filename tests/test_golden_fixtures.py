@@ -1,0 +1,42 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the CPU
+oracle): the oracle must keep reproducing them (CPU), and the HIP path must reproduce them without
+the oracle or the reference being present (GPU)."""
+import numpy as np
+import pytest
+
+from tests.golden_util import check_against_golden, load
+
+CASES = [("sdf_80x60_128.npz", 0), ("ofusion_80x60_128.npz", 1)]
+
+
+@pytest.mark.parametrize("name,field", CASES, ids=["sdf", "ofusion"])
+def test_oracle_reproduces_golden(name, field):
+    from oracle.binding import OraclePipeline
+    g = load(name)
+    W, H, N, F = (int(v) for v in g["dims"])
+    o = OraclePipeline(field, N, float(g["dim"]), W, H)
+    for f in range(F):
+        o.integrate(g["depth"][f], g["pose"][f], g["k"], float(g["mu"]), f)
+        ran, v, n = o.raycast(g["pose"][f], g["k"], float(g["mu"]), f)
+    c, x, y, a = o.blocks()
+    code, side, nx, ny = o.nodes()
+    check_against_golden(g, c, x, y, a, code, nx, ny, v, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,field", CASES, ids=["sdf", "ofusion"])
+@pytest.mark.parametrize("max_blocks", [0, 4096], ids=["dense", "pooled"])
+def test_hip_reproduces_golden(name, field, max_blocks):
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    g = load(name)
+    W, H, N, F = (int(v) for v in g["dims"])
+    p = DenseSLAMPipeline((W, H), N, float(g["dim"]), field_type=field, max_blocks=max_blocks)
+    for f in range(F):
+        p.set_depth(g["depth"][f]); p.setPose(g["pose"][f])
+        p.integration(g["k"], 1, float(g["mu"]), f)
+        p.raycasting(g["k"], float(g["mu"]), f)
+    v, n = p.vertex_normal()
+    c, x, y, a = p.blocks()
+    code, side, nx, ny = p.nodes()
+    check_against_golden(g, c, x, y, a, code, nx, ny, v, n)
+    p.close()

@@ -1,0 +1,115 @@
+"""Full-size, oracle-free checks of the HIP path through size-independent properties
+(BASELINE.json configs[1], [3]-geometry and [4]): analytic-surface error of the raycast, map
+invariants, ancestor closure of the index, determinism, dense-vs-pooled equivalence, read-only raycast."""
+import numpy as np
+import pytest
+
+from supereight_amd.pipeline import OFUSION, SDF, DenseSLAMPipeline
+from supereight_amd.synthetic import SyntheticStream, surface_distance
+
+pytestmark = pytest.mark.gpu
+
+
+def run(field, W, H, N, dim, mu, frames, **kw):
+    s = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim, field_type=field, **kw)
+    for f in range(frames):
+        p.set_depth(s.depth(f)); p.setPose(s.pose(f))
+        assert p.integration(s.k, 1, mu, f)
+        p.raycasting(s.k, mu, f)
+    return p
+
+
+def map_invariants(p, field, N, frames):
+    c, x, y, a = p.blocks()
+    code, side, nx, ny = p.nodes()
+    assert len(c) > 0 and (c % 8 == 0).all() and (c >= 0).all() and (c < N).all()
+    assert len(np.unique(c, axis=0)) == len(c)                       # every block allocated once
+    assert np.isfinite(x).all() and np.isfinite(y).all()
+    if field == SDF:
+        assert x.min() >= -1 and x.max() <= 1
+        assert y.min() >= 0 and y.max() <= min(frames, 100) and (y == np.round(y)).all()   # weight = number of fusions
+    else:
+        assert x.min() >= -1000 and x.max() <= 1000
+        ts = np.float32(1.0 / 30.0) * np.arange(frames, dtype=np.float32)
+        assert np.isin(y, ts).all()                                   # last-update time is one of the frame time stamps
+    # ancestor closure: the parent octant of every block and node exists (Octree::allocate_level)
+    max_level = int(np.log2(N))
+    keys = set(int(k) for k in code)
+    def parent(k):
+        lvl = (k & 0x1FF) - 1
+        if lvl == 0:
+            return 0
+        sh = 3 * (max_level - lvl)
+        return ((k & ~0x1FF) >> sh << sh) | lvl
+    from supereight_amd.synthetic import to_colmajor  # noqa: F401  (keeps the import surface of the package exercised)
+    leaf = max_level - 3
+    def key_of(cx, cy, cz, lvl):
+        k = 0
+        for i in range(max_level):
+            k |= ((int(cx) >> i) & 1) << (3 * i) | ((int(cy) >> i) & 1) << (3 * i + 1) | ((int(cz) >> i) & 1) << (3 * i + 2)
+        return k | lvl
+    for cx, cy, cz in c[:: max(1, len(c) // 2000)]:
+        assert parent(key_of(cx, cy, cz, leaf)) in keys
+    for k in list(keys)[:: max(1, len(keys) // 2000)]:
+        if k & 0x1FF:
+            assert parent(k) in keys
+    assert side[0] == N and code[0] == 0                               # root
+    return c, x, y, a
+
+
+@pytest.mark.parametrize("field,mu,frames", [(SDF, 0.1, 30), (OFUSION, 0.008, 12)], ids=["sdf", "ofusion"])
+def test_640x480_512_properties(field, mu, frames):
+    W, H, N, dim = 640, 480, 512, 4.8
+    p = run(field, W, H, N, dim, mu, frames)
+    v, n = p.vertex_normal()
+    v2, n2 = (p.raycasting(SyntheticStream(W, H, dim).k, mu, frames - 1), p.vertex_normal())[1]
+    assert (v.view(np.uint32) == v2.view(np.uint32)).all() and (n.view(np.uint32) == n2.view(np.uint32)).all()   # raycast is read-only
+    hit = n[..., 0] != -2
+    assert 0.80 * W * H < hit.sum() < 0.95 * W * H
+    assert np.allclose(np.linalg.norm(n[hit], axis=-1), 1, atol=1e-5)
+    assert (v[~hit] == 0).all() and (n[~hit][:, 1:] == 0).all()
+    d = surface_distance(v[hit], dim)
+    voxel = dim / N
+    print(f"surface error: mean {1e3 * d.mean():.3f} mm, median {1e3 * np.median(d):.3f} mm, p99 {1e3 * np.percentile(d, 99):.2f} mm, hits {hit.sum()}")
+    if field == SDF:      # reference mean 0.98 mm, p99 3.6 mm at frame 5
+        assert d.mean() < 1.5e-3 and np.percentile(d, 99) < 6e-3
+    else:
+        assert d.mean() < 1.5 * voxel and np.percentile(d, 99) < 4 * voxel
+    c, x, y, a = map_invariants(p, field, N, frames)
+    q = run(field, W, H, N, dim, mu, frames, max_blocks=40000)        # pooled mode, and a second run: determinism
+    c2, x2, y2, a2 = q.blocks()
+    assert (c == c2).all() and (x.view(np.uint32) == x2.view(np.uint32)).all() and (y.view(np.uint32) == y2.view(np.uint32)).all() and (a == a2).all()
+    v3, n3 = q.vertex_normal()
+    assert (v.view(np.uint32) == v3.view(np.uint32)).all() and (n.view(np.uint32) == n3.view(np.uint32)).all()
+    p.close(); q.close()
+
+
+def test_1280x960_2048_properties():
+    """BASELINE.json configs[3] geometry on one GPU: 64 GiB dense brick grid vs a 1 M-block pool."""
+    W, H, N, dim, mu, frames = 1280, 960, 2048, 4.8, 0.1, 5
+    p = run(SDF, W, H, N, dim, mu, frames)
+    nb, nn = p.counts()
+    assert 350_000 < nb < 600_000                                     # SURVEY: ~402 k blocks after frame 0
+    v, n = p.vertex_normal()
+    hit = n[..., 0] != -2
+    d = surface_distance(v[hit], dim)
+    print(f"2048^3: blocks {nb}, hits {hit.sum()}, surface error mean {1e3 * d.mean():.3f} mm p99 {1e3 * np.percentile(d, 99):.2f} mm")
+    assert hit.sum() > 0.8 * W * H and d.mean() < 1.0e-3
+    q = run(SDF, W, H, N, dim, mu, frames, max_blocks=1 << 20)
+    assert q.counts() == (nb, nn)
+    v2, n2 = q.vertex_normal()
+    assert (v.view(np.uint32) == v2.view(np.uint32)).all() and (n.view(np.uint32) == n2.view(np.uint32)).all()
+    p.close(); q.close()
+
+
+def test_pool_exhaustion_is_reported():
+    from supereight_amd.pipeline import SeHipError
+    W, H, N, dim = 160, 120, 256, 2.4
+    s = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim, max_blocks=100)
+    p.set_depth(s.depth(0)); p.setPose(s.pose(0))
+    p.integration(s.k, 1, 0.1, 0)
+    with pytest.raises(SeHipError, match="pool exhausted"):
+        p.counts()
+    p.close()
