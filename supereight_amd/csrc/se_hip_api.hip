@@ -164,11 +164,8 @@ void make_logodds(const std::vector<float>& lut, std::vector<float>& tab) {
 }
 
 int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlists, long long stride_words) {
-  HIP_TRY(hipMemsetAsync(p->chain, 0xFF, 4 * sizeof(unsigned long long), p->stream));
   ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
-  for (int j = 0; j < 3; ++j)
-    hipLaunchKernelGGL(k_min_key, dim3(64), dim3(SE_WG), 0, p->stream, lists, nlists, stride_words, p->chain + j, p->chain + (j ? j - 1 : 0), j ? 1 : 0);
-  hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(64), 0, p->stream, p->map, p->chain);
+  hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(SE_WG), 0, p->stream, p->map, lists, nlists, stride_words);
   return SE_HIP_OK;
 }
 

@@ -7,7 +7,7 @@
 
 #define SE_WG 256
 #define SE_SPEC 4     // SDF march: samples fetched per memory round trip
-#define SE_SPEC_OF 4  // OFusion march: samples fetched per memory round trip
+#define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
 
 // ------------------------------------------------------------------------------------------
 // index insertion (replaces Octree::allocate / allocate_level, se_core/include/se/octree.hpp:792-856)
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_scan_ofusion(DevMap m, const fl
       f3 voxelPos = origin;
       const float fsize = (float)m.size;
       const float hf_band = a.band, half = a.band * 0.5f;
+      int llvl = -1, lox = -1, loy = -1, loz = -1;  // last octant handled (probing it again changes nothing)
       for (float travelled = 0.f; travelled < dist; travelled += stepsize) {
         const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
         const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
@@ -170,11 +171,14 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_scan_ofusion(DevMap m, const fl
           const int lvl = tree_depth < m.leaf_level ? tree_depth : m.leaf_level;  // fetch_octant stops at the leaves
           const int sh = m.max_level - lvl;
           const int ox = (int)vx >> sh, oy = (int)vy >> sh, oz = (int)vz >> sh;
-          const uint32_t e = m.tab[tab_index(m, lvl, ox, oy, oz)];
-          if (e == 0u) {
-            if (se_insert_octant(m, lvl, ox, oy, oz)) { se_append_key(m, lvl, ox, oy, oz); ++newk; }
-          } else if (tree_depth >= m.leaf_level && e != SE_PENDING) {
-            se_mark_active(m, e - 1u, a.sharded != 0, ox, oy, oz);
+          if (lvl != llvl || ox != lox || oy != loy || oz != loz) {
+            llvl = lvl; lox = ox; loy = oy; loz = oz;
+            const uint32_t e = m.tab[tab_index(m, lvl, ox, oy, oz)];
+            if (e == 0u) {
+              if (se_insert_octant(m, lvl, ox, oy, oz)) { se_append_key(m, lvl, ox, oy, oz); ++newk; }
+            } else if (tree_depth >= m.leaf_level && e != SE_PENDING) {
+              se_mark_active(m, e - 1u, a.sharded != 0, ox, oy, oz);
+            }
           }
         }
         // compute_stepsize / step_to_depth (alloc_impl.hpp:37-51); the three depths are
@@ -244,32 +248,44 @@ __global__ __launch_bounds__(SE_WG) void k_occ_commit(DevMap m) { se_occ_commit(
 
 // unique_multiscale keeps keys[0] whatever its level (se_core/include/se/algorithms/unique.hpp:64-79):
 // when the smallest key of a frame's list (after filter_ancestors) is a coarse octant, the
-// reference walks it down to the leaves along child 0.  k_min_key finds the smallest key greater
-// than `lower` over the frame's key list(s) (3 passes resolve the ancestor chain), k_zero_chain
-// inserts that chain.
-__global__ __launch_bounds__(SE_WG) void k_min_key(const unsigned long long* __restrict__ lists, int nlists, long long stride_words,
-                                                    unsigned long long* out, const unsigned long long* lower_ptr, int has_lower) {
-  const unsigned long long lower = has_lower ? *lower_ptr : 0ull;
-  unsigned long long best = ~0ull;
-  for (int li = 0; li < nlists; ++li) {
-    const unsigned long long* list = lists + (long long)li * stride_words;
-    unsigned long long n = list[0];
-    if (n > (unsigned long long)(stride_words - 1)) n = (unsigned long long)(stride_words - 1);
-    for (unsigned long long i = blockIdx.x * (unsigned long long)SE_WG + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * SE_WG) {
-      const unsigned long long k = list[1 + i];
-      if (k & SE_KEY_ACTIVATE) continue;
-      if ((!has_lower || k > lower) && k < best) best = k;
+// reference walks it down to the leaves along child 0.  k_zero_chain finds the three smallest
+// distinct keys of the frame's key list(s) (they resolve the ancestor chain that filter_ancestors
+// collapses) and inserts that chain.
+// One workgroup: three passes "smallest key greater than the previous" over the list(s), then the
+// chain insertion by thread 0.
+__global__ __launch_bounds__(SE_WG) void k_zero_chain(DevMap m, const unsigned long long* __restrict__ lists, int nlists, long long stride_words) {
+  __shared__ unsigned long long s_best[SE_WG / 64];
+  __shared__ unsigned long long s_chain[3];
+  unsigned long long lower = 0ull;
+  for (int pass = 0; pass < 3; ++pass) {
+    unsigned long long best = ~0ull;
+    for (int li = 0; li < nlists; ++li) {
+      const unsigned long long* list = lists + (long long)li * stride_words;
+      unsigned long long n = list[0];
+      if (n > (unsigned long long)(stride_words - 1)) n = (unsigned long long)(stride_words - 1);
+      for (unsigned long long i = threadIdx.x; i < n; i += SE_WG) {
+        const unsigned long long k = list[1 + i];
+        if (k & SE_KEY_ACTIVATE) continue;
+        if ((pass == 0 || k > lower) && k < best) best = k;
+      }
     }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_down(best, o); if (v < best) best = v; }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long b = s_best[0];
+      for (int w = 1; w < SE_WG / 64; ++w) if (s_best[w] < b) b = s_best[w];
+      s_chain[pass] = b;
+    }
+    __syncthreads();
+    lower = s_chain[pass];
+    if (lower == ~0ull) break;
   }
-  for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_down(best, o); if (v < best) best = v; }
-  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(out, best);
-}
-__global__ void k_zero_chain(DevMap m, const unsigned long long* chain /* k0,k1,k2 candidates */) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned long long cur = chain[0];
+  if (threadIdx.x != 0) return;
+  unsigned long long cur = s_chain[0];
   if (cur == ~0ull) return;
   for (int j = 1; j < 3; ++j) {
-    const unsigned long long nx = chain[j];
+    const unsigned long long nx = s_chain[j];
     if (nx == ~0ull) break;
     // descendant(nx, cur): octant_ops.hpp:81-88
     const int lvl = (int)(cur & 0x1FFull);
