@@ -50,6 +50,7 @@ def parse():
                     help="record per-kernel HIP events on every n-th timed frame (1 = every frame; events cost host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30, help="timed frames of the CPU baseline sample")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU baseline sample (median is reported)")
     ap.add_argument("--detail", type=str, default="", help="write a detailed JSON report to this path")
     return ap.parse_args()
 
@@ -77,26 +78,51 @@ def cpu_baseline(args, n_timed: int):
     except Exception:
         native = False
     field = binding.SDF if args.field == "sdf" else binding.OFUSION
-    o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
-    threads = o.lib.so_num_threads()
-    s = SyntheticStream(args.width, args.height, args.dim)
-    t_sum, t_int_sum, t_ray_sum = 0.0, 0.0, 0.0
-    for f in range(4 + n_timed):
-        d, pose = s.depth(f), s.pose(f)
-        t0 = time.perf_counter()
-        o.integrate(d, pose, s.k, args.mu, f)
-        t1 = time.perf_counter()
-        o.raycast(pose, s.k, args.mu, f)
-        t2 = time.perf_counter()
-        if f >= 4:
-            t_int_sum += t1 - t0
-            t_ray_sum += t2 - t1
-    t_sum = t_int_sum + t_ray_sum
-    o.close()
-    return {"value": n_timed / t_sum, "unit": "frames/s", "cores": int(threads), "kind": "port",
+    reps = []
+    for _ in range(max(1, args.cpu_reps)):
+        o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
+        threads = o.lib.so_num_threads()
+        s = SyntheticStream(args.width, args.height, args.dim)
+        t_int_sum, t_ray_sum = 0.0, 0.0
+        for f in range(4 + n_timed):
+            d, pose = s.depth(f), s.pose(f)
+            t0 = time.perf_counter()
+            o.integrate(d, pose, s.k, args.mu, f)
+            t1 = time.perf_counter()
+            o.raycast(pose, s.k, args.mu, f)
+            t2 = time.perf_counter()
+            if f >= 4:
+                t_int_sum += t1 - t0
+                t_ray_sum += t2 - t1
+        o.close()
+        reps.append((n_timed / (t_int_sum + t_ray_sum), t_int_sum, t_ray_sum))
+    reps.sort()
+    fps, t_int_sum, t_ray_sum = reps[len(reps) // 2]          # median repetition
+    return {"value": fps, "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"frames 4..{3 + n_timed} of the same synthetic stream after 4 executed warm-up frames "
-                      f"({n_timed} timed frames, OpenMP {threads} threads, {'-march=native' if native else '-march=x86-64-v3'} build)",
-            "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed}
+                      f"({n_timed} timed frames, median of {len(reps)} repetitions, OpenMP {threads} threads, "
+                      f"{'-march=native' if native else '-march=x86-64-v3'} build)",
+            "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed,
+            "all_repetitions_fps": [r[0] for r in reps]}
+
+
+def pmc_traffic(kernel: str, args):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this exact
+    workload (profiles/*_pmc_traffic.json, written by tools/summarize_prof.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md); None
+    if there is none -- counters cannot be collected from inside bench.py."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("width"), w.get("height"), w.get("res"), w.get("field")) == (args.width, args.height, args.res, args.field):
+            if kernel in d.get("kernels", {}):
+                best = (d["kernels"][kernel]["traffic_bytes"], os.path.basename(path))
+    return best
 
 
 def main():
@@ -218,6 +244,10 @@ def main():
                               "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                               "avg_launch_us": per_kernel[dom]["avg_us"],
                               "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes"]}
+        tr = pmc_traffic(dom, args)
+        if tr:
+            result["roofline"]["traffic"] = tr[0]
+            result["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr[1]
         result["kernels"] = per_kernel
         result["work_per_frame"] = {kk: st[kk] / K for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
 

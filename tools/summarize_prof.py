@@ -78,3 +78,32 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_cache"):
             cells.append(f"{sum(v) / len(v):.4g}" if v else "-")
         print(f"| {k} | {n} | " + " | ".join(cells) + " |")
     print()
+
+# HBM traffic per launch = 2 * FETCH_SIZE (gfx950: the counter reports half of the bytes of a coalesced
+# read, MI355X_MICROARCH.md section HBM; confirmed here on k_integrate, whose 2*FETCH + WRITE matches its
+# algorithmic bytes) + WRITE_SIZE (calibrated on k_fill: 1.05 GB reported for 1.074 GB stored); counters are KB.
+import json
+fetch, write = {}, {}
+for sub, dst in (("pmc_fetch", fetch), ("pmc_write", write)):
+    files = find(sub, "*counter_collection.csv")
+    if not files:
+        continue
+    acc = defaultdict(list)
+    with open(files[0]) as fh:
+        for row in csv.DictReader(fh):
+            if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        v = v[14:] if len(v) > 20 else v
+        dst[k] = sum(v) / len(v)
+names = {"k_alloc_scan": "alloc_scan", "k_integrate": "integrate", "k_raycast": "raycast"}
+kern = {}
+for k in fetch:
+    for pre, nice in names.items():
+        if k.startswith(pre) and k in write:
+            kern[nice] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k],
+                          "traffic_bytes": (2.0 * fetch[k] + write[k]) * 1024.0}
+wl = {"width": int(os.environ.get("SE_PROF_W", 640)), "height": int(os.environ.get("SE_PROF_H", 480)),
+      "res": int(os.environ.get("SE_PROF_RES", 512)), "field": os.environ.get("SE_PROF_FIELD", "sdf")}
+with open(os.path.join(out_dir, "pmc_traffic.json"), "w") as fh:
+    json.dump({"workload": wl, "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE) KB", "kernels": kern}, fh, indent=1)
