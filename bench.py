@@ -143,9 +143,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    backend = os.environ.get("SE_BENCH_BACKEND", "nccl")     # "gloo": dry run of the N > 1 path with all ranks on one GPU
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     field = SDF if args.field == "sdf" else OFUSION
     W, H, N, dim, mu = args.width, args.height, args.res, args.dim, args.mu
     warm = max(args.warmup, 4)   # frames 0..3 are the reference's own warm-up (forced integration, no raycast before frame 3)
@@ -184,7 +190,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timings = sp.p.timings(reset=True) if not args.no_events else None

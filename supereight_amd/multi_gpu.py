@@ -93,7 +93,13 @@ class ShardedPipeline:
             if self.world > 1:
                 import torch.distributed as dist
                 recv = self.recv[: self.world * words]
-                dist.all_gather_into_tensor(recv, self.send[:words], group=self.group)
+                if dist.get_backend(self.group) == "gloo":
+                    # dry-run transport (several ranks sharing one GPU, no RCCL): stage through the host
+                    host = exchange_key_lists(self.send[:words].cpu(), self.world, self.group)
+                    recv.copy_(host)
+                    self.torch.cuda.synchronize()
+                else:
+                    dist.all_gather_into_tensor(recv, self.send[:words], group=self.group)
                 p.alloc_commit(recv.data_ptr(), self.world, words)
             p.integrate_sweep(k, integration_rate, mu, frame)
         p.raycasting(k, mu, frame)
