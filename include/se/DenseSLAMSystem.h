@@ -8,14 +8,14 @@
  * What is kept (same names, argument meaning and "did the stage run" return values):
  *   the two constructors, preprocessing() (mm -> metres, preprocessing.cpp:161-188, fused into the
  *   upload; the bilateral filter is outside the path this library implements), integration(),
- *   raycasting(), setPose()/getPose()/getPosition()/getInitPos(), getIntegrated(),
+ *   tracking(), raycasting(), setPose()/getPose()/getPosition()/getInitPos(), getIntegrated(), getTracked(),
  *   getModelDimensions()/getModelResolution()/getComputationResolution(), synchroniseDevices().
  * What differs, because the map lives in HBM:
  *   getMap() returns a host snapshot (MapSnapshot: blocks sorted by Morton key) instead of a
  *   shared_ptr<se::Octree>; getVertex()/getNormal() download vertex_/normal_.
- *   tracking() and the render*() methods are not part of this path: tracking()
- *   returns false and leaves the pose alone -- inject poses with setPose(), as the reference's GUI does
- *   with ground truth (se_apps/src/mainQt.cpp:257-265).
+ *   tracking() runs the reference's ICP on the device; poses can still be injected
+ *   with setPose(), as the reference's GUI does with ground truth (se_apps/src/mainQt.cpp:257-265).
+ *   The render*() methods are not implemented.
  * Errors of the C ABI are reported like the reference reports its own failures: message on
  * std::cerr; constructors additionally throw std::runtime_error (the reference would dereference
  * an unallocated map).
@@ -103,7 +103,8 @@ class DenseSLAMSystem {
                   const Eigen::Vector3f& volumeDimensions, const Eigen::Matrix4f& initPose, std::vector<int>& pyramid,
                   const Configuration& config)
       : computation_size_(inputSize), volume_resolution_(volumeResolution), volume_dimension_(volumeDimensions) {
-    (void)pyramid;
+    iterations_.assign(pyramid.begin(), pyramid.end());
+    if (iterations_.empty()) iterations_ = {10, 5, 4};
     init_pose_ = Eigen::Vector3f(initPose(0, 3), initPose(1, 3), initPose(2, 3));
     mu_ = config.mu;
     pose_ = initPose;
@@ -127,8 +128,13 @@ class DenseSLAMSystem {
   /* the reference's float_depth_ handed over directly (metres) */
   bool preprocessing(const float* depthMetres) { return ok(se_hip_upload_depth(h_, depthMetres)); }
 
-  /* DenseSLAMSystem.h:173 -- not on this path; poses are injected with setPose() */
-  bool tracking(const Eigen::Vector4f&, float, unsigned, unsigned) { tracked_ = false; return false; }
+  /* DenseSLAMSystem.h:173 / DenseSLAMSystem.cpp:143-189: ICP against the last raycast, on the device */
+  bool tracking(const Eigen::Vector4f& k, float icp_threshold, unsigned tracking_rate, unsigned frame) {
+    const int r = se_hip_track(h_, k.data(), icp_threshold, tracking_rate, frame, iterations_.data(), (int32_t)iterations_.size(), pose_.data());
+    ok(r);
+    tracked_ = r > 0;
+    return tracked_;
+  }
 
   /* DenseSLAMSystem.h:193 / DenseSLAMSystem.cpp:206-268 */
   bool integration(const Eigen::Vector4f& k, unsigned int integration_rate, float mu, unsigned int frame) {
@@ -194,6 +200,7 @@ class DenseSLAMSystem {
   Eigen::Vector3f init_pose_;
   Eigen::Matrix4f pose_, raycast_pose_;
   float mu_ = 0.1f;
+  std::vector<int32_t> iterations_;
   bool tracked_ = false, integrated_ = false;
   friend void synchroniseDevices();
 };

@@ -107,6 +107,19 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose[16], const float k[4], f
 int se_hip_download_vertex_normal(se_hip_pipeline* p, float* host_vertex_xyz, float* host_normal_xyz);
 int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, float** device_normal_xyz);
 
+/* ---- "next" row f-2: bool DenseSLAMSystem::tracking(const Vector4f& k, float icp_threshold,
+ *      unsigned tracking_rate, unsigned frame)  (DenseSLAMSystem.h:173, DenseSLAMSystem.cpp:143-189):
+ *      half-sample pyramid of the current depth image, depth2vertex / vertex2normal per level, ICP
+ *      (trackKernel + reduceKernel on the device, updatePoseKernel's 6x6 solve + SE3 exp on the host)
+ *      against vertex_ / normal_ of the last se_hip_raycast, checkPoseKernel.
+ *      pose_inout = pose_ (updated in place; restored if the check fails); pyramid = iterations per
+ *      level, finest first (default {10, 5, 4}).  Returns 1 = tracked, 0 = gated off or rejected. */
+int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame,
+                 const int32_t* pyramid, int32_t n_levels, float pose_inout[16]);
+/* tracking_result_ (TrackData {int result; float error; float J[6];} per pixel, commons.h:249-253) and
+ * row 0 of reduction_output_ (32 floats) of the last ICP iteration; iterations run in the last call. */
+int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_reduce32[32], int32_t* iterations);
+
 /* ---- map read-back: what getMap() exposes as a host se::Octree
  *      (DenseSLAMSystem.h:295; se_core/include/se/octree.hpp:898-914 save layout). */
 int se_hip_counts(se_hip_pipeline* p, int32_t* n_blocks, int32_t* n_nodes);

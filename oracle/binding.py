@@ -94,6 +94,12 @@ def _declare(lib):
         "so_pipe_get_nodes": (None, [vp, c_u64p, c_u32p, c_f32p, c_f32p]),
         "so_pipe_stats": (None, [vp, c_u64p]),
         "so_pipe_timings": (None, [vp, c_f64p]),
+        "so_half_sample": (None, [c_f32p, i32, i32, c_f32p, i32, f32, i32]),
+        "so_depth2vertex": (None, [c_f32p, c_f32p, i32, i32, c_f32p]),
+        "so_vertex2normal": (None, [c_f32p, c_f32p, i32, i32, i32]),
+        "so_se3_exp": (None, [c_f32p, c_f32p]),
+        "so_solve6": (i32, [c_f32p, c_f32p]),
+        "so_tracking": (i32, [c_f32p, i32, i32, c_f32p, c_i32p, i32, f32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, C.POINTER(i32)]),
         "so_num_threads": (i32, []),
         "so_set_num_threads": (None, [i32]),
     }
@@ -213,3 +219,22 @@ class OraclePipeline:
         out = np.zeros(4, np.float64)
         self.lib.so_pipe_timings(self.h, out)
         return dict(zip(("alloc_scan", "allocate", "sweep", "raycast"), out.tolist()))
+
+
+TRACK_DTYPE = np.dtype([("result", np.int32), ("error", np.float32), ("J", np.float32, 6)])
+
+
+def oracle_tracking(depth, k, pose, raycast_pose, ref_vertex, ref_normal, icp_threshold=1e-5, pyramid=(10, 5, 4)):
+    """DenseSLAMSystem::tracking on the oracle.  Returns (tracked, new_pose 4x4, TrackData image, reduce row, iterations)."""
+    from supereight_amd.synthetic import to_colmajor
+    lib = load()
+    H, W = depth.shape
+    pose_cm = to_colmajor(pose).copy()
+    track = np.zeros(W * H, TRACK_DTYPE)
+    red = np.zeros(32, np.float32)
+    it = C.c_int()
+    ok = lib.so_tracking(np.ascontiguousarray(depth, np.float32).reshape(-1), W, H, np.asarray(k, np.float32),
+                         np.asarray(pyramid, np.int32), len(pyramid), icp_threshold,
+                         np.ascontiguousarray(ref_vertex, np.float32).reshape(-1), np.ascontiguousarray(ref_normal, np.float32).reshape(-1),
+                         to_colmajor(raycast_pose), pose_cm, track.ctypes.data, red, C.byref(it))
+    return bool(ok), pose_cm.reshape(4, 4).T.copy(), track.reshape(H, W), red, it.value

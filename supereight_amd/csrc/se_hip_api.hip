@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "se_kernels.h"
+#include "se_track_kernels.h"
 
 namespace {
 
@@ -71,6 +72,14 @@ struct se_hip_pipeline {
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool upload_on_side = false; // the current depth image was uploaded on `side`
   bool occ_commit_due = false; // the next sweep kernel must publish the scan's occupancy bits
+  // tracking
+  float raycast_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // column-major, pose of the last raycast
+  std::vector<float*> pyr_depth, pyr_vertex, pyr_normal;  // level 0 depth aliases the current depth image
+  TrackData* track = nullptr;
+  float* reduce_partial = nullptr;
+  float* reduce_out = nullptr;       // 8 x 32
+  float* reduce_host = nullptr;      // pinned, 8 x 32
+  int track_iterations = 0;
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
@@ -167,6 +176,80 @@ int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlis
   ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
   hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(SE_WG), 0, p->stream, p->map, lists, nlists, stride_words);
   return SE_HIP_OK;
+}
+
+
+// ---- updatePoseKernel's host arithmetic (tracking.cpp:42-65, 304-318): makeJTJ + LLT solve, SE3 exp.
+// Eigen::LLT / Sophus::SE3f::exp are defined as: unblocked Cholesky with left-to-right inner sums; the
+// Sophus 1.0 closed form with epsilon 1e-5f and sinf / cosf from the C library.
+bool solve6(const float* vals /*b[6], upper triangle[21]*/, float x[6]) {
+  float Cm[6][6], L[6][6];
+  int k = 6;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) { Cm[r][c] = vals[k]; Cm[c][r] = vals[k]; ++k; }
+  for (int j = 0; j < 6; ++j) {
+    float d = Cm[j][j];
+    if (j > 0) { float sn = 0; for (int q = 0; q < j; ++q) sn += L[j][q] * L[j][q]; d -= sn; }
+    if (!(d > 0.f)) { for (int i = 0; i < 6; ++i) x[i] = 0.f; return false; }
+    d = std::sqrt(d);
+    L[j][j] = d;
+    for (int i = j + 1; i < 6; ++i) {
+      float v = Cm[i][j];
+      if (j > 0) { float sp = 0; for (int q = 0; q < j; ++q) sp += L[i][q] * L[j][q]; v -= sp; }
+      L[i][j] = v / d;
+    }
+  }
+  float yv[6];
+  for (int i = 0; i < 6; ++i) { float v = vals[i]; for (int q = 0; q < i; ++q) v -= L[i][q] * yv[q]; yv[i] = v / L[i][i]; }
+  for (int i = 5; i >= 0; --i) { float v = yv[i]; for (int q = i + 1; q < 6; ++q) v -= L[q][i] * x[q]; x[i] = v / L[i][i]; }
+  return true;
+}
+M4 se3_exp(const float a[6]) {
+  const float eps = 1e-5f;
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = (ox * ox + oy * oy) + oz * oz, theta = std::sqrt(theta_sq), half_theta = 0.5f * theta;
+  float imag_factor, real_factor;
+  if (theta_sq < eps * eps) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+    real_factor = 1.f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+  } else {
+    imag_factor = sinf(half_theta) / theta;
+    real_factor = cosf(half_theta);
+  }
+  float qw = real_factor, qx = imag_factor * ox, qy = imag_factor * oy, qz = imag_factor * oz;
+  const float qn = std::sqrt(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+  const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const float R[3][3] = {{1.f - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1.f - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1.f - (txx + tyy)}};
+  float V[3][3];
+  if (theta < eps) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = R[i][j];
+  } else {
+    const float Om[3][3] = {{0, -oz, oy}, {oz, 0, -ox}, {-oy, ox, 0}};
+    float Om2[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Om2[i][j] = (Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j]) + Om[i][2] * Om[2][j];
+    const float ca = (1.f - cosf(theta)) / theta_sq, cb = (theta - sinf(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) V[i][j] = ((i == j ? 1.f : 0.f) + ca * Om[i][j]) + cb * Om2[i][j];
+  }
+  M4 T{};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T.m[i][j] = R[i][j];
+    T.m[i][3] = (V[i][0] * a[0] + V[i][1] * a[1]) + V[i][2] * a[2];
+  }
+  T.m[3][3] = 1.f;
+  return T;
+}
+M4 rigid_inverse(const M4& a) {   // raycast_pose_.inverse() of a rigid transform (DenseSLAMSystem.cpp:164)
+  M4 r{};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+  for (int i = 0; i < 3; ++i) r.m[i][3] = -((r.m[i][0] * a.m[0][3] + r.m[i][1] * a.m[1][3]) + r.m[i][2] * a.m[2][3]);
+  r.m[3][3] = 1.f;
+  return r;
 }
 
 // Overlap mode: depth uploads go to the side stream, behind the previous sweep (the last reader of
@@ -351,6 +434,13 @@ int se_hip_destroy(se_hip_pipeline* p) {
   void* ptrs[] = {m.occ, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain};
   for (void* q : ptrs) if (q) hipFree(q);
+  for (auto* q : p->pyr_depth) if (q) hipFree(q);
+  for (auto* q : p->pyr_vertex) if (q) hipFree(q);
+  for (auto* q : p->pyr_normal) if (q) hipFree(q);
+  if (p->track) hipFree(p->track);
+  if (p->reduce_partial) hipFree(p->reduce_partial);
+  if (p->reduce_out) hipFree(p->reduce_out);
+  if (p->reduce_host) hipHostFree(p->reduce_host);
   if (p->ctr_host) hipHostFree(p->ctr_host);
   if (p->side) hipStreamDestroy(p->side);
   if (p->ev_sweep) hipEventDestroy(p->ev_sweep);
@@ -573,6 +663,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (!pose_cm || !k) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!(frame > 2)) return 0;  // DenseSLAMSystem.cpp:195
   if (int r = join_scan(p)) return r;
+  std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   const DevMap& m = p->map;
   const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));  // DenseSLAMSystem.cpp:199
   RayArgs a{};
@@ -639,6 +730,97 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** v, float** n) {
   if (int r = check(p)) return r;
   if (v) *v = p->vertex;
   if (n) *n = p->normal;
+  return SE_HIP_OK;
+}
+
+
+// -------------------------------------------------------------------------------------- tracking
+int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame,
+                 const int32_t* pyramid, int32_t n_levels, float pose_cm[16]) {
+  if (int r = check(p)) return r;
+  if (!k || !pose_cm || !pyramid || n_levels < 1 || n_levels > 8 || tracking_rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (frame % tracking_rate != 0) return 0;   // DenseSLAMSystem.cpp:146
+  if (int r = join_scan(p)) return r;
+  const int W = p->cfg.width, H = p->cfg.height;
+  if ((W >> (n_levels - 1)) < 1 || (H >> (n_levels - 1)) < 1) return fail(SE_HIP_E_INVALID, "too many pyramid levels");
+  hipStream_t s = p->stream;
+  // buffers (first call)
+  if ((int)p->pyr_vertex.size() < n_levels) {
+    p->pyr_depth.resize(n_levels, nullptr); p->pyr_vertex.resize(n_levels, nullptr); p->pyr_normal.resize(n_levels, nullptr);
+    for (int i = 0; i < n_levels; ++i) {
+      const size_t n = (size_t)(W >> i) * (H >> i);
+      if (i > 0 && !p->pyr_depth[i]) HIP_TRY(hipMalloc((void**)&p->pyr_depth[i], n * sizeof(float)));
+      if (!p->pyr_vertex[i]) { HIP_TRY(hipMalloc((void**)&p->pyr_vertex[i], n * 3 * sizeof(float))); HIP_TRY(hipMemsetAsync(p->pyr_vertex[i], 0, n * 3 * sizeof(float), s)); }
+      if (!p->pyr_normal[i]) { HIP_TRY(hipMalloc((void**)&p->pyr_normal[i], n * 3 * sizeof(float))); HIP_TRY(hipMemsetAsync(p->pyr_normal[i], 0, n * 3 * sizeof(float), s)); }
+    }
+  }
+  if (!p->track) {
+    HIP_TRY(hipMalloc((void**)&p->track, (size_t)W * H * sizeof(TrackData)));
+    HIP_TRY(hipMemsetAsync(p->track, 0, (size_t)W * H * sizeof(TrackData), s));
+    HIP_TRY(hipMalloc((void**)&p->reduce_partial, 8 * SE_TRACK_SEGMENTS * 32 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&p->reduce_out, 8 * 32 * sizeof(float)));
+    HIP_TRY(hipHostMalloc((void**)&p->reduce_host, 8 * 32 * sizeof(float)));
+  }
+  // pyramid (DenseSLAMSystem.cpp:149-163): scaled_depth_[0] is the current depth image
+  const float* d0 = p->depth;
+  for (int i = 1; i < n_levels; ++i) {
+    const int w = W >> i, h = H >> i;
+    const float* src = i == 1 ? d0 : p->pyr_depth[i - 1];
+    hipLaunchKernelGGL(k_half_sample, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_depth[i], w, h, src, W >> (i - 1), 0.1f * 3, 1);   // e_delta * 3
+  }
+  for (int i = 0; i < n_levels; ++i) {
+    const int w = W >> i, h = H >> i;
+    const float kk[4] = {k[0] / float(1 << i), k[1] / float(1 << i), k[2] / float(1 << i), k[3] / float(1 << i)};
+    const M4 invK = inverse_camera_matrix(kk);
+    InvK ik;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) ik.m[r * 4 + c] = invK.m[r][c];
+    const float* dsrc = i == 0 ? d0 : p->pyr_depth[i];
+    hipLaunchKernelGGL(k_depth2vertex, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_vertex[i], dsrc, w, h, ik);
+    hipLaunchKernelGGL(k_vertex2normal, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_normal[i], p->pyr_vertex[i], w, h, k[1] < 0 ? 1 : 0);
+  }
+  M4 pose = from_colmajor(pose_cm);
+  const M4 old_pose = pose;
+  const M4 projectReference = mul(camera_matrix(k), rigid_inverse(from_colmajor(p->raycast_pose)));
+  TrackArgs a{};
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) a.view[r * 4 + c] = projectReference.m[r][c];
+  a.dist_threshold = 0.1f; a.normal_threshold = 0.8f;   // constant_parameters.h:19-20
+  a.refW = W; a.refH = H;
+  int done = 0;
+  bool converged = false;
+  for (int level = n_levels - 1; level >= 0; --level) {
+    const int w = W / (1 << level), h = H / (1 << level);
+    a.inW = w; a.inH = h;
+    for (int i = 0; i < pyramid[level]; ++i) {
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) a.T[r * 4 + c] = pose.m[r][c];
+      hipLaunchKernelGGL(k_track, dim3((w + 255) / 256, h), dim3(256), 0, s, p->track, p->pyr_vertex[level], p->pyr_normal[level], p->vertex, p->normal, a);
+      hipLaunchKernelGGL(k_track_reduce, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->reduce_partial, p->track, W, w, h);
+      hipLaunchKernelGGL(k_track_reduce_final, dim3(1), dim3(32), 0, s, p->reduce_out, p->reduce_partial);
+      HIP_TRY(hipMemcpyAsync(p->reduce_host, p->reduce_out, 8 * 32 * sizeof(float), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      ++done;
+      float x[6];
+      solve6(p->reduce_host + 1, x);
+      pose = mul(se3_exp(x), pose);          // updatePoseKernel: pose = delta * pose
+      float xn = 0; for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
+      if (std::sqrt(xn) < icp_threshold) { converged = true; break; }
+    }
+    (void)converged;
+  }
+  p->track_iterations = done;
+  // checkPoseKernel (tracking.cpp:320-334)
+  const float* v = p->reduce_host;
+  bool tracked = true;
+  if ((std::sqrt(v[0] / v[28]) > 2e-2) || (v[28] / (W * H) < 0.15f)) { pose = old_pose; tracked = false; }
+  for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) pose_cm[c * 4 + r] = pose.m[r][c];
+  return tracked ? 1 : 0;
+}
+
+int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_reduce32[32], int32_t* iterations) {
+  if (int r = check(p)) return r;
+  if (!p->track) return fail(SE_HIP_E_INVALID, "se_hip_track has not run");
+  if (host_trackdata) HIP_TRY(hipMemcpy(host_trackdata, p->track, (size_t)p->cfg.width * p->cfg.height * sizeof(TrackData), hipMemcpyDeviceToHost));
+  if (host_reduce32) std::memcpy(host_reduce32, p->reduce_host, 32 * sizeof(float));
+  if (iterations) *iterations = p->track_iterations;
   return SE_HIP_OK;
 }
 

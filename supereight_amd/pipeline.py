@@ -53,6 +53,8 @@ EXPORTS = {
     "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "se_hip_track": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int32, _f32p]),
+    "se_hip_download_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "se_hip_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "se_hip_download_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "se_hip_download_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -154,6 +156,23 @@ class DenseSLAMPipeline:
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_raycast(self._h, _colmajor(self.pose_), np.asarray(k, np.float32), mu, frame)))
+
+    TRACK_DTYPE = np.dtype([("result", np.int32), ("error", np.float32), ("J", np.float32, 6)])
+
+    def tracking(self, k, icp_threshold: float, tracking_rate: int, frame: int, pyramid=(10, 5, 4)) -> bool:
+        """DenseSLAMSystem::tracking: ICP of the current depth image against the last raycast; updates pose_."""
+        pose_cm = _colmajor(self.pose_).copy()
+        r = self._check(self.lib.se_hip_track(self._h, np.asarray(k, np.float32), icp_threshold, tracking_rate, frame,
+                                              np.asarray(pyramid, np.int32), len(pyramid), pose_cm))
+        self.pose_ = pose_cm.reshape(4, 4).T.copy()
+        return bool(r)
+
+    def track_data(self):
+        t = np.zeros(self.W * self.H, self.TRACK_DTYPE)
+        red = np.zeros(32, np.float32)
+        it = C.c_int32()
+        self._check(self.lib.se_hip_download_track(self._h, t.ctypes.data, red.ctypes.data, C.byref(it)))
+        return t.reshape(self.H, self.W), red, it.value
 
     # stage split used by the multi-GPU driver
     def alloc_scan(self, k, integration_rate: int, mu: float, frame: int) -> bool:

@@ -1,0 +1,77 @@
+"""ICP tracking on the device against the oracle -- the full SLAM loop
+(preprocessing -> tracking -> integration -> raycasting) with poses estimated by the tracker instead of
+injected.  Pyramid, TrackData, reduction sums, pose updates and the accept / reject decision are
+compared bit for bit (oracle and HIP path share one summation order and one LLT / SE3-exp definition)."""
+import numpy as np
+import pytest
+
+from oracle.binding import OFUSION, SDF, OraclePipeline, oracle_tracking
+from supereight_amd.pipeline import DenseSLAMPipeline
+from supereight_amd.synthetic import SyntheticStream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("field,W,H,N,dim,mu,frames", [(SDF, 320, 240, 256, 4.8, 0.1, 9), (SDF, 640, 480, 512, 4.8, 0.1, 7),
+                                                         (OFUSION, 320, 240, 256, 4.8, 0.02, 7)], ids=["sdf-320", "sdf-640", "ofusion-320"])
+def test_slam_loop_with_tracking(field, W, H, N, dim, mu, frames):
+    s = SyntheticStream(W, H, dim)
+    cpu = OraclePipeline(field, N, dim, W, H)
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field)
+    pose_c = s.pose(0).copy()
+    gpu.setPose(s.pose(0))
+    v_c = n_c = rp_c = None
+    tracked_frames = 0
+    for f in range(frames):
+        depth = s.depth(f)
+        gpu.set_depth(depth)
+        if f >= 4:   # the reference apps track from frame 1 on; the first frames here build a map with GT poses
+            ok_c, pose_c, track_c, red_c, it_c = oracle_tracking(depth, s.k, pose_c, rp_c, v_c, n_c, 1e-5, (10, 5, 4))
+            ok_g = gpu.tracking(s.k, 1e-5, 1, f, (10, 5, 4))
+            track_g, red_g, it_g = gpu.track_data()
+            assert ok_g == ok_c and it_g == it_c
+            assert (track_g["result"] == track_c["result"]).all()
+            good = track_c["result"] == 1
+            assert (track_g["error"][good].view(np.uint32) == track_c["error"][good].view(np.uint32)).all()
+            assert (track_g["J"][good].view(np.uint32) == track_c["J"][good].view(np.uint32)).all()
+            assert (red_g.view(np.uint32) == red_c.view(np.uint32)).all(), (red_g, red_c)
+            assert (gpu.getPose().view(np.uint32) == pose_c.view(np.uint32)).all()
+            assert ok_c and 0.5 * W * H < red_c[28]          # most pixels are inliers on this scene
+            tracked_frames += 1
+        else:
+            pose_c = s.pose(f).copy()
+            gpu.setPose(pose_c)
+        cpu.integrate(depth, pose_c, s.k, mu, f)
+        gpu.integration(s.k, 1, mu, f)
+        ran, vv, nn = cpu.raycast(pose_c, s.k, mu, f)
+        gpu.raycasting(s.k, mu, f)
+        if ran:
+            v_c, n_c, rp_c = vv, nn, pose_c.copy()
+            v_g, n_g = gpu.vertex_normal()
+            assert (v_g.view(np.uint32) == v_c.view(np.uint32)).all() and (n_g.view(np.uint32) == n_c.view(np.uint32)).all()
+    assert tracked_frames == frames - 4
+    # the tracker follows the camera: pose error stays within a fraction of a voxel / of the per-frame motion
+    err = np.abs(pose_c - s.pose(frames - 1)).max()
+    print("pose error after", tracked_frames, "tracked frames:", err)
+    assert err < 0.02
+    cc, cx, cy, ca = cpu.blocks()
+    gc, gx, gy, ga = gpu.blocks()
+    assert (cc == gc).all() and (cx.view(np.uint32) == gx.view(np.uint32)).all() and (cy.view(np.uint32) == gy.view(np.uint32)).all()
+    cpu.close(); gpu.close()
+
+
+def test_tracking_gate_and_rejection():
+    W, H, N, dim = 160, 120, 128, 2.4
+    s = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim)
+    for f in range(4):
+        p.set_depth(s.depth(f)); p.setPose(s.pose(f))
+        p.integration(s.k, 1, 0.1, f); p.raycasting(s.k, 0.1, f)
+    p.set_depth(s.depth(4))
+    assert p.tracking(s.k, 1e-5, 2, 5) is False            # frame % tracking_rate != 0
+    before = p.getPose()
+    far = before.copy(); far[:3, 3] += 1.0                   # a pose from which nothing overlaps: checkPoseKernel must restore it
+    p.setPose(far)
+    assert p.tracking(s.k, 1e-5, 1, 4) is False
+    assert (p.getPose() == far).all()
+    p.close()
