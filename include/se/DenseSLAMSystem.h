@@ -9,13 +9,14 @@
  *   the two constructors, preprocessing() (mm -> metres, preprocessing.cpp:161-188, fused into the
  *   upload; the bilateral filter is outside the path this library implements), integration(),
  *   tracking(), raycasting(), setPose()/getPose()/getPosition()/getInitPos(), getIntegrated(), getTracked(),
- *   getModelDimensions()/getModelResolution()/getComputationResolution(), synchroniseDevices().
+ *   getModelDimensions()/getModelResolution()/getComputationResolution(), renderVolume()/renderTrack()/
+ *   renderDepth(), setViewPose()/getViewPose(), synchroniseDevices().
  * What differs, because the map lives in HBM:
  *   getMap() returns a host snapshot (MapSnapshot: blocks sorted by Morton key) instead of a
  *   shared_ptr<se::Octree>; getVertex()/getNormal() download vertex_/normal_.
  *   tracking() runs the reference's ICP on the device; poses can still be injected
  *   with setPose(), as the reference's GUI does with ground truth (se_apps/src/mainQt.cpp:257-265).
- *   The render*() methods are not implemented.
+ *   renderVolume / renderTrack / renderDepth shade on the device and copy the RGBW image out.
  * Errors of the C ABI are reported like the reference reports its own failures: message on
  * std::cerr; constructors additionally throw std::runtime_error (the reference would dereference
  * an unallocated map).
@@ -151,6 +152,17 @@ class DenseSLAMSystem {
     return r > 0;
   }
 
+  /* DenseSLAMSystem.h:241-286 / DenseSLAMSystem.cpp:274-300: RGBW images of the computation size */
+  void renderVolume(unsigned char* out, const Eigen::Vector2i& outputSize, int frame, int raycast_rendering_rate,
+                    const Eigen::Vector4f& k, float largestep) {
+    (void)outputSize;
+    ok(se_hip_render_volume(h_, out, viewPose_->data(), k.data(), mu_, largestep, (uint32_t)frame, (uint32_t)raycast_rendering_rate));
+  }
+  void renderTrack(unsigned char* out, const Eigen::Vector2i& outputSize) { (void)outputSize; ok(se_hip_render_track(h_, out)); }
+  void renderDepth(unsigned char* out, const Eigen::Vector2i& outputSize) { (void)outputSize; ok(se_hip_render_depth(h_, out)); }
+  void setViewPose(Eigen::Matrix4f* value = NULL) { viewPose_ = value ? value : &pose_; }   /* DenseSLAMSystem.h:363-372 */
+  Eigen::Matrix4f* getViewPose() { return viewPose_; }
+
   void getMap(MapSnapshot& out) {
     int nb = 0, nn = 0;
     if (!ok(se_hip_counts(h_, &nb, &nn))) return;
@@ -199,6 +211,7 @@ class DenseSLAMSystem {
   Eigen::Vector3f volume_dimension_;
   Eigen::Vector3f init_pose_;
   Eigen::Matrix4f pose_, raycast_pose_;
+  Eigen::Matrix4f* viewPose_ = &pose_;
   float mu_ = 0.1f;
   std::vector<int32_t> iterations_;
   bool tracked_ = false, integrated_ = false;

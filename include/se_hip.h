@@ -120,6 +120,16 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
  * row 0 of reduction_output_ (32 floats) of the last ICP iteration; iterations run in the last call. */
 int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_reduce32[32], int32_t* iterations);
 
+/* ---- "next" row f-3: the render*() methods (DenseSLAMSystem.h:241-286, DenseSLAMSystem.cpp:274-300;
+ *      kernels se_denseslam/src/rendering.cpp:111-283).  Output: width*height RGBW bytes (host).
+ *      se_hip_render_volume: view_pose = *viewPose_ (re-raycasts with far = 2*farPlane when it is not
+ *      approximately raycast_pose_, else shades vertex_/normal_); light = its translation, ambient 0.1;
+ *      mu = the constructor's config.mu; returns 1 = rendered, 0 = gated off (frame % rate != 0). */
+int se_hip_render_volume(se_hip_pipeline* p, uint8_t* host_rgbw, const float view_pose[16], const float k[4], float mu, float largestep,
+                         uint32_t frame, uint32_t raycast_rendering_rate);
+int se_hip_render_depth(se_hip_pipeline* p, uint8_t* host_rgbw);
+int se_hip_render_track(se_hip_pipeline* p, uint8_t* host_rgbw);
+
 /* ---- map read-back: what getMap() exposes as a host se::Octree
  *      (DenseSLAMSystem.h:295; se_core/include/se/octree.hpp:898-914 save layout). */
 int se_hip_counts(se_hip_pipeline* p, int32_t* n_blocks, int32_t* n_nodes);

@@ -100,6 +100,9 @@ def _declare(lib):
         "so_se3_exp": (None, [c_f32p, c_f32p]),
         "so_solve6": (i32, [c_f32p, c_f32p]),
         "so_tracking": (i32, [c_f32p, i32, i32, c_f32p, c_i32p, i32, f32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, C.POINTER(i32)]),
+        "so_render_depth": (None, [c_u8p, c_f32p, i32, i32]),
+        "so_render_track": (None, [c_u8p, C.c_void_p, i32, i32]),
+        "so_pipe_render_volume": (None, [vp, c_u8p, c_f32p, c_f32p, c_f32p, f32, f32, c_f32p, c_f32p]),
         "so_num_threads": (i32, []),
         "so_set_num_threads": (None, [i32]),
     }
@@ -184,6 +187,14 @@ class OraclePipeline:
         ran = bool(self.lib.so_pipe_raycast(self.h, to_colmajor(pose), np.asarray(k, np.float32), mu, frame,
                                             v.reshape(-1), n.reshape(-1)))
         return ran, v, n
+
+    def render_volume(self, view_pose, raycast_pose, k, mu, largestep, vertex, normal):
+        from supereight_amd.synthetic import to_colmajor
+        out = np.zeros((self.H, self.W, 4), np.uint8)
+        self.lib.so_pipe_render_volume(self.h, out.reshape(-1), to_colmajor(view_pose), to_colmajor(raycast_pose), np.asarray(k, np.float32),
+                                       mu, largestep, np.ascontiguousarray(vertex, np.float32).reshape(-1),
+                                       np.ascontiguousarray(normal, np.float32).reshape(-1))
+        return out
 
     def counts(self):
         nb, nn = C.c_int(), C.c_int()

@@ -80,6 +80,7 @@ struct se_hip_pipeline {
   float* reduce_out = nullptr;       // 8 x 32
   float* reduce_host = nullptr;      // pinned, 8 x 32
   int track_iterations = 0;
+  unsigned char* rgbw = nullptr;   // render target (W*H*4)
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
@@ -250,6 +251,46 @@ M4 rigid_inverse(const M4& a) {   // raycast_pose_.inverse() of a rigid transfor
   for (int i = 0; i < 3; ++i) r.m[i][3] = -((r.m[i][0] * a.m[0][3] + r.m[i][1] * a.m[1][3]) + r.m[i][2] * a.m[2][3]);
   r.m[3][3] = 1.f;
   return r;
+}
+
+struct RayLaunchArgs { RayArgs a; size_t smem; dim3 grid; };
+
+// RayArgs of raycastKernel for pose * K^-1 (DenseSLAMSystem.cpp:197-200)
+RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const float k[4], float mu) {
+  RayLaunchArgs L{};
+  const DevMap& m = p->map;
+  const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));  // DenseSLAMSystem.cpp:199
+  RayArgs& a = L.a;
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) a.view3[i * 3 + j] = view.m[i][j]; a.org[i] = view.m[i][3]; }
+  a.nearp = 0.4f; a.farp = 4.0f;  // constant_parameters.h:22-32
+  a.mu = mu;
+  a.step = m.dim / (float)m.size;           // DenseSLAMSystem.cpp:197
+  a.largestep = a.step * 8;                 // step * BLOCK_SIDE
+  a.inv_voxel = (float)m.size / m.dim;      // volume_template.hpp:78
+  a.grad_scale = 0.5f * m.dim / (float)m.size;  // octree.hpp:736
+  a.epsilon = exp2f(-(float)p->max_level);  // ray_iterator.hpp:63
+  a.min_scale = 23 - p->leaf_level;         // ray_iterator.hpp:62
+  a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_ROWS")) {  // diagnostic: raycast only rows [b,e)
+    int b = 0, e = 0;
+    if (std::sscanf(ev, "%d,%d", &b, &e) == 2 && b >= 0 && e > b && e <= a.H) { a.row_begin = b; a.row_end = e; }
+  }
+  // occupancy levels staged in LDS: levels 1..5 (4.7 KB; measured: level 6 = +32 KB costs more
+  // occupancy and staging time than the leaf-level bit tests it saves) unless overridden
+  int cl = p->ray_cache_levels >= 0 ? p->ray_cache_levels : 5;
+  cl = std::min(cl, p->leaf_level);
+  a.cache_levels = cl;
+  // staged region = words [0, end of level cl)
+  a.cache_words = cl > 0 ? (int)(occ_woff(cl) + std::max<size_t>(1, ((size_t)1 << (3 * cl)) / 32)) : 1;
+  a.stack_depth = p->leaf_level;
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
+  // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
+  // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
+  a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
+  L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG) * sizeof(uint32_t);
+  const int tiles = ((a.W + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
+  L.grid = dim3((tiles + 3) / 4);
+  return L;
 }
 
 // Overlap mode: depth uploads go to the side stream, behind the previous sweep (the last reader of
@@ -438,6 +479,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto* q : p->pyr_vertex) if (q) hipFree(q);
   for (auto* q : p->pyr_normal) if (q) hipFree(q);
   if (p->track) hipFree(p->track);
+  if (p->rgbw) hipFree(p->rgbw);
   if (p->reduce_partial) hipFree(p->reduce_partial);
   if (p->reduce_out) hipFree(p->reduce_out);
   if (p->reduce_host) hipHostFree(p->reduce_host);
@@ -665,37 +707,10 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (int r = join_scan(p)) return r;
   std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   const DevMap& m = p->map;
-  const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));  // DenseSLAMSystem.cpp:199
-  RayArgs a{};
-  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) a.view3[i * 3 + j] = view.m[i][j]; a.org[i] = view.m[i][3]; }
-  a.nearp = 0.4f; a.farp = 4.0f;  // constant_parameters.h:22-32
-  a.mu = mu;
-  a.step = m.dim / (float)m.size;           // DenseSLAMSystem.cpp:197
-  a.largestep = a.step * 8;                 // step * BLOCK_SIDE
-  a.inv_voxel = (float)m.size / m.dim;      // volume_template.hpp:78
-  a.grad_scale = 0.5f * m.dim / (float)m.size;  // octree.hpp:736
-  a.epsilon = exp2f(-(float)p->max_level);  // ray_iterator.hpp:63
-  a.min_scale = 23 - p->leaf_level;         // ray_iterator.hpp:62
-  a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_ROWS")) {  // diagnostic: raycast only rows [b,e)
-    int b = 0, e = 0;
-    if (std::sscanf(ev, "%d,%d", &b, &e) == 2 && b >= 0 && e > b && e <= a.H) { a.row_begin = b; a.row_end = e; }
-  }
-  // occupancy levels staged in LDS: levels 1..5 (4.7 KB; measured: level 6 = +32 KB costs more
-  // occupancy and staging time than the leaf-level bit tests it saves) unless overridden
-  int cl = p->ray_cache_levels >= 0 ? p->ray_cache_levels : 5;
-  cl = std::min(cl, p->leaf_level);
-  a.cache_levels = cl;
-  // staged region = words [0, end of level cl)
-  a.cache_words = cl > 0 ? (int)(occ_woff(cl) + std::max<size_t>(1, ((size_t)1 << (3 * cl)) / 32)) : 1;
-  a.stack_depth = p->leaf_level;
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
-  // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
-  // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
-  a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
-  const size_t smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG) * sizeof(uint32_t);
-  const int tiles = ((a.W + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
-  const dim3 grid((tiles + 3) / 4), block(SE_WG);
+  const RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
+  const RayArgs& a = L.a;
+  const size_t smem = L.smem;
+  const dim3 grid = L.grid, block(SE_WG);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   {
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
@@ -822,6 +837,71 @@ int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_r
   if (host_reduce32) std::memcpy(host_reduce32, p->reduce_host, 32 * sizeof(float));
   if (iterations) *iterations = p->track_iterations;
   return SE_HIP_OK;
+}
+
+
+// -------------------------------------------------------------------------------------- rendering
+static int render_target(se_hip_pipeline* p) {
+  if (!p->rgbw) HIP_TRY(hipMalloc((void**)&p->rgbw, (size_t)p->cfg.width * p->cfg.height * 4));
+  return SE_HIP_OK;
+}
+static int render_download(se_hip_pipeline* p, uint8_t* host) {
+  HIP_TRY(hipMemcpyAsync(host, p->rgbw, (size_t)p->cfg.width * p->cfg.height * 4, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return SE_HIP_OK;
+}
+
+int se_hip_render_volume(se_hip_pipeline* p, uint8_t* host_rgbw, const float view_cm[16], const float k[4], float mu, float largestep,
+                         uint32_t frame, uint32_t rate) {
+  if (int r = check(p)) return r;
+  if (!host_rgbw || !view_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (frame % rate != 0) return 0;   // DenseSLAMSystem.cpp:281
+  if (int r = join_scan(p)) return r;
+  if (int r = render_target(p)) return r;
+  RayLaunchArgs L = make_ray_args(p, view_cm, k, mu);
+  L.a.farp = 4.0f * 2.0f;            // farPlane * 2.0f (DenseSLAMSystem.cpp:285)
+  L.a.largestep = largestep;
+  L.a.row_begin = 0; L.a.row_end = p->cfg.height;
+  ShadeArgs sh{};
+  sh.light[0] = view_cm[12]; sh.light[1] = view_cm[13]; sh.light[2] = view_cm[14];
+  sh.ambient[0] = sh.ambient[1] = sh.ambient[2] = 0.1f;   // constant_parameters.h:37
+  // !viewPose_->isApprox(raycast_pose_): Eigen's fuzzy compare, ||a-b||^2 <= 1e-10 * min(||a||^2, ||b||^2)
+  float d2 = 0, na = 0, nb = 0;
+  for (int i = 0; i < 16; ++i) { const float d = view_cm[i] - p->raycast_pose[i]; d2 += d * d; na += view_cm[i] * view_cm[i]; nb += p->raycast_pose[i] * p->raycast_pose[i]; }
+  sh.render = !(d2 <= 1e-5f * 1e-5f * std::min(na, nb)) ? 1 : 0;
+  const int tiles = ((L.a.W + 7) / 8) * ((L.a.H + 7) / 8);
+  const dim3 grid((tiles + 3) / 4), block(SE_WG);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  const DevMap& m = p->map;
+  if (sdf) { if (m.dense) hipLaunchKernelGGL((k_render_volume<false, true>), grid, block, 0, p->stream, m, L.a, sh, p->vertex, p->normal, p->rgbw);
+             else hipLaunchKernelGGL((k_render_volume<false, false>), grid, block, 0, p->stream, m, L.a, sh, p->vertex, p->normal, p->rgbw); }
+  else { if (m.dense) hipLaunchKernelGGL((k_render_volume<true, true>), grid, block, 0, p->stream, m, L.a, sh, p->vertex, p->normal, p->rgbw);
+         else hipLaunchKernelGGL((k_render_volume<true, false>), grid, block, 0, p->stream, m, L.a, sh, p->vertex, p->normal, p->rgbw); }
+  HIP_TRY(hipGetLastError());
+  if (int r = render_download(p, host_rgbw)) return r;
+  return 1;
+}
+
+int se_hip_render_depth(se_hip_pipeline* p, uint8_t* host_rgbw) {
+  if (int r = check(p)) return r;
+  if (!host_rgbw) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (int r = join_scan(p)) return r;
+  if (int r = render_target(p)) return r;
+  const int n = p->cfg.width * p->cfg.height;
+  hipLaunchKernelGGL(k_render_depth, dim3((n + 255) / 256), dim3(256), 0, p->stream, p->rgbw, p->depth, n, 0.4f, 4.0f);
+  HIP_TRY(hipGetLastError());
+  return render_download(p, host_rgbw);
+}
+
+int se_hip_render_track(se_hip_pipeline* p, uint8_t* host_rgbw) {
+  if (int r = check(p)) return r;
+  if (!host_rgbw) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!p->track) return fail(SE_HIP_E_INVALID, "se_hip_track has not run");
+  if (int r = render_target(p)) return r;
+  const int n = p->cfg.width * p->cfg.height;
+  hipLaunchKernelGGL(k_render_track, dim3((n + 255) / 256), dim3(256), 0, p->stream, p->rgbw, p->track, n);
+  HIP_TRY(hipGetLastError());
+  return render_download(p, host_rgbw);
 }
 
 // ----------------------------------------------------------------------------------- read-back

@@ -748,6 +748,146 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   return {t_min * m.dim, tmax_m};
 }
 
+// raycast(const Volume<T>&, origin, direction, tnear, tfar, mu, step, largestep)
+// (se_denseslam/src/kfusion/rendering_impl.hpp:34-74, bfusion/rendering_impl.hpp:35-68): writes the hit
+// (position, distance) or leaves it zero.  Shared by the raycast kernel and the volume renderer.
+struct RayCounters { unsigned long long n_get, n_interp; };
+template <bool OFUSION, bool STATS, bool DENSE>
+__device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
+                                            BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  unsigned long long& n_get = rc.n_get;
+  unsigned long long& n_interp = rc.n_interp;
+  {
+    const float tnear = t_min;
+    if (!OFUSION) {
+      // raycast(const Volume<SDF>&...) (se_denseslam/src/kfusion/rendering_impl.hpp:34-74)
+      if (tnear < tfar) {
+        float t = tnear;
+        float stepsize = a.largestep;
+        f3 position = f3_add(org, f3_scale_r(dir, t));
+        float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
+        if (STATS) ++n_interp;
+        float f_tt = 0;
+        if (f_t > 0) {
+          // The march is a chain of dependent memory round trips (sample -> step size -> next
+          // position).  Most steps repeat the previous step size (largestep through unobserved
+          // space, mu through observed free space where tsdf == 1), so SE_SPEC samples at
+          // position + k * S * dir are fetched in one round trip and consumed in order for as long
+          // as the step actually taken equals the predicted S bit for bit -- the positions are
+          // formed by the same float additions the sequential loop performs.
+          float S = a.largestep;
+          bool done = false;
+          for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+            f3 q[SE_SPEC];
+            uint32_t qe[SE_SPEC];
+            float qx[SE_SPEC], qy[SE_SPEC];
+            int qi[SE_SPEC][3];
+            q[0] = position;
+#pragma unroll
+            for (int i = 1; i < SE_SPEC; ++i) q[i] = f3_add(q[i - 1], f3_scale(S, dir));
+#pragma unroll
+            for (int i = 0; i < SE_SPEC; ++i) {
+              // VolumeTemplate::get -> get_fine (volume_template.hpp:77-83)
+              qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
+              qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < SE_SPEC; ++i) {
+              const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
+              qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
+            }
+#pragma unroll
+            for (int i = 0; i < SE_SPEC; ++i) {
+              if (!(t < tfar)) { done = true; break; }
+              if (STATS) ++n_get;
+              const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
+              if (dy == 0) {
+                stepsize = a.largestep;
+                position = f3_add(position, f3_scale(stepsize, dir));
+              } else {
+                f_tt = dx;
+                if ((double)f_tt <= 0.1 && f_tt >= -0.5f) {
+                  c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
+                  f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
+                  if (STATS) ++n_interp;
+                }
+                if (f_tt < 0) { done = true; break; }
+                stepsize = fmaxf(f_tt * a.mu, a.step);
+                position = f3_add(position, f3_scale(stepsize, dir));
+                f_t = f_tt;
+              }
+              t += stepsize;
+              if (stepsize != S) { S = stepsize; break; }
+            }
+          }
+          if (f_tt < 0) {
+            t = t + stepsize * f_tt / (f_t - f_tt);
+            const f3 r = f3_add(org, f3_scale_r(dir, t));
+            hx = r.x; hy = r.y; hz = r.z; hw = t;
+          }
+        }
+      }
+    } else {
+      // raycast(const Volume<OFusion>&...) (se_denseslam/src/bfusion/rendering_impl.hpp:35-68)
+      if (tnear < tfar) {
+        float t = tnear;
+        const float stepsize = a.step;
+        float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
+        if (STATS) ++n_interp;
+        float f_tt = 0;
+        if (f_t <= 0.f) {
+          // fixed step: every sample position origin + dir * t_k with t_k+1 = t_k + step is known in
+          // advance, so SE_SPEC_OF gets share one memory round trip
+          bool done = false;
+          for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+            float tt[SE_SPEC_OF];
+            f3 q[SE_SPEC_OF];
+            uint32_t qe[SE_SPEC_OF];
+            float qx[SE_SPEC_OF], qy[SE_SPEC_OF];
+            int qi[SE_SPEC_OF][3];
+            tt[0] = t;
+#pragma unroll
+            for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
+#pragma unroll
+            for (int i = 0; i < SE_SPEC_OF; ++i) {
+              q[i] = f3_add(org, f3_scale_r(dir, tt[i]));
+              qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
+              qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < SE_SPEC_OF; ++i) {
+              const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
+              qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
+            }
+            bool stop = false;
+#pragma unroll
+            for (int i = 0; i < SE_SPEC_OF; ++i) {
+              if (stop) continue;
+              t = tt[i];
+              if (!(t < tfar)) { done = true; stop = true; continue; }
+              if (STATS) ++n_get;
+              const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
+              if (dx > -100.f && dy > 0.f) {
+                c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
+                f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
+                if (STATS) ++n_interp;
+              }
+              if (f_tt > 0.f) { done = true; stop = true; continue; }
+              f_t = f_tt;
+            }
+            if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
+          }
+          if (f_tt > 0.f) {
+            t = t - stepsize * (f_tt - 0.f) / (f_tt - f_t);
+            const f3 r = f3_add(org, f3_scale_r(dir, t));
+            hx = r.x; hy = r.y; hz = r.z; hw = t;
+          }
+        }
+      }
+    }
+  }
+}
+
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
 template <bool OFUSION, bool STATS, bool DENSE>
@@ -783,133 +923,9 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
     float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
     BlkCache c = {-1, -1, -1, 0u};
     if (t_min > 0.f && !(a.debug_phases & 1)) {
-      const float tnear = t_min;
-      if (!OFUSION) {
-        // raycast(const Volume<SDF>&...) (se_denseslam/src/kfusion/rendering_impl.hpp:34-74)
-        if (tnear < tfar) {
-          float t = tnear;
-          float stepsize = a.largestep;
-          f3 position = f3_add(org, f3_scale_r(dir, t));
-          float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
-          if (STATS) ++n_interp;
-          float f_tt = 0;
-          if (f_t > 0) {
-            // The march is a chain of dependent memory round trips (sample -> step size -> next
-            // position).  Most steps repeat the previous step size (largestep through unobserved
-            // space, mu through observed free space where tsdf == 1), so SE_SPEC samples at
-            // position + k * S * dir are fetched in one round trip and consumed in order for as long
-            // as the step actually taken equals the predicted S bit for bit -- the positions are
-            // formed by the same float additions the sequential loop performs.
-            float S = a.largestep;
-            bool done = false;
-            for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
-              f3 q[SE_SPEC];
-              uint32_t qe[SE_SPEC];
-              float qx[SE_SPEC], qy[SE_SPEC];
-              int qi[SE_SPEC][3];
-              q[0] = position;
-#pragma unroll
-              for (int i = 1; i < SE_SPEC; ++i) q[i] = f3_add(q[i - 1], f3_scale(S, dir));
-#pragma unroll
-              for (int i = 0; i < SE_SPEC; ++i) {
-                // VolumeTemplate::get -> get_fine (volume_template.hpp:77-83)
-                qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
-                qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
-              }
-#pragma unroll
-              for (int i = 0; i < SE_SPEC; ++i) {
-                const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
-                qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
-              }
-#pragma unroll
-              for (int i = 0; i < SE_SPEC; ++i) {
-                if (!(t < tfar)) { done = true; break; }
-                if (STATS) ++n_get;
-                const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
-                if (dy == 0) {
-                  stepsize = a.largestep;
-                  position = f3_add(position, f3_scale(stepsize, dir));
-                } else {
-                  f_tt = dx;
-                  if ((double)f_tt <= 0.1 && f_tt >= -0.5f) {
-                    c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
-                    f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
-                    if (STATS) ++n_interp;
-                  }
-                  if (f_tt < 0) { done = true; break; }
-                  stepsize = fmaxf(f_tt * a.mu, a.step);
-                  position = f3_add(position, f3_scale(stepsize, dir));
-                  f_t = f_tt;
-                }
-                t += stepsize;
-                if (stepsize != S) { S = stepsize; break; }
-              }
-            }
-            if (f_tt < 0) {
-              t = t + stepsize * f_tt / (f_t - f_tt);
-              const f3 r = f3_add(org, f3_scale_r(dir, t));
-              hx = r.x; hy = r.y; hz = r.z; hw = t;
-            }
-          }
-        }
-      } else {
-        // raycast(const Volume<OFusion>&...) (se_denseslam/src/bfusion/rendering_impl.hpp:35-68)
-        if (tnear < tfar) {
-          float t = tnear;
-          const float stepsize = a.step;
-          float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
-          if (STATS) ++n_interp;
-          float f_tt = 0;
-          if (f_t <= 0.f) {
-            // fixed step: every sample position origin + dir * t_k with t_k+1 = t_k + step is known in
-            // advance, so SE_SPEC_OF gets share one memory round trip
-            bool done = false;
-            for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
-              float tt[SE_SPEC_OF];
-              f3 q[SE_SPEC_OF];
-              uint32_t qe[SE_SPEC_OF];
-              float qx[SE_SPEC_OF], qy[SE_SPEC_OF];
-              int qi[SE_SPEC_OF][3];
-              tt[0] = t;
-#pragma unroll
-              for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
-#pragma unroll
-              for (int i = 0; i < SE_SPEC_OF; ++i) {
-                q[i] = f3_add(org, f3_scale_r(dir, tt[i]));
-                qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
-                qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
-              }
-#pragma unroll
-              for (int i = 0; i < SE_SPEC_OF; ++i) {
-                const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
-                qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
-              }
-              bool stop = false;
-#pragma unroll
-              for (int i = 0; i < SE_SPEC_OF; ++i) {
-                if (stop) continue;
-                t = tt[i];
-                if (!(t < tfar)) { done = true; stop = true; continue; }
-                if (STATS) ++n_get;
-                const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
-                if (dx > -100.f && dy > 0.f) {
-                  c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
-                  f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
-                  if (STATS) ++n_interp;
-                }
-                if (f_tt > 0.f) { done = true; stop = true; continue; }
-                f_t = f_tt;
-              }
-              if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
-            }
-            if (f_tt > 0.f) {
-              t = t - stepsize * (f_tt - 0.f) / (f_tt - f_t);
-              const f3 r = f3_add(org, f3_scale_r(dir, t));
-              hx = r.x; hy = r.y; hz = r.z; hw = t;
-            }
-          }
-        }
-      }
+      RayCounters rc = {0ull, 0ull};
+      se_cast_ray<OFUSION, STATS, DENSE>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+      if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
     }
     if (STATS) tk3 = __builtin_amdgcn_s_memtime();
     float* v = vertex + 3 * (size_t)(px + py * a.W);
@@ -966,4 +982,116 @@ __global__ void k_fill(float* __restrict__ p, float v, size_t n) {
 __global__ void k_mm2meters(float* __restrict__ out, int ow, int oh, const unsigned short* __restrict__ in, int iw, int ratio) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x < ow && y < oh) out[x + ow * y] = in[x * ratio + iw * y * ratio] / 1000.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// renderVolumeKernel / renderDepthKernel / renderTrackKernel
+// (se_denseslam/src/rendering.cpp:111-283), RGBW 8-bit images
+// ------------------------------------------------------------------------------------------
+// ray_iterator's tmin() / tmax() (ray_iterator.hpp:53-102, 232-240): entry / exit of the volume cube
+// clamped to the near / far planes -- what renderVolumeKernel uses (it does not advance to a leaf)
+__device__ __forceinline__ RaySpan se_ray_range(const DevMap& m, const RayArgs& a, f3 origin, f3 direction) {
+  const float eps = a.epsilon;
+  f3 d;
+  d.x = fabsf(direction.x) < eps ? copysignf(eps, direction.x) : direction.x;
+  d.y = fabsf(direction.y) < eps ? copysignf(eps, direction.y) : direction.y;
+  d.z = fabsf(direction.z) < eps ? copysignf(eps, direction.z) : direction.z;
+  const f3 scaled_origin = f3_add(f3_div(origin, m.dim), {1.f, 1.f, 1.f});
+  const f3 t_coef = f3_scale(-1.f, {1.f / fabsf(d.x), 1.f / fabsf(d.y), 1.f / fabsf(d.z)});
+  f3 t_bias = f3_mul(t_coef, scaled_origin);
+  if (d.x > 0.0f) t_bias.x = 3.0f * t_coef.x - t_bias.x;
+  if (d.y > 0.0f) t_bias.y = 3.0f * t_coef.y - t_bias.y;
+  if (d.z > 0.0f) t_bias.z = 3.0f * t_coef.z - t_bias.z;
+  float t_min = fmaxf(fmaxf(2.0f * t_coef.x - t_bias.x, 2.0f * t_coef.y - t_bias.y), 2.0f * t_coef.z - t_bias.z);
+  float t_max = fminf(fminf(t_coef.x - t_bias.x, t_coef.y - t_bias.y), t_coef.z - t_bias.z);
+  t_min = fmaxf(t_min, a.nearp / m.dim);
+  t_max = fminf(t_max, a.farp / m.dim);
+  return {t_min * m.dim, t_max * m.dim};
+}
+
+struct ShadeArgs { float light[3], ambient[3]; int render; };
+
+// renderVolumeKernel (rendering.cpp:215-283)
+template <bool OFUSION, bool DENSE>
+__global__ __launch_bounds__(SE_WG) void k_render_volume(DevMap m, RayArgs a, ShadeArgs sh, const float* __restrict__ vertex,
+                                                         const float* __restrict__ normal, unsigned char* __restrict__ out) {
+  const FieldConst fc = se_field_const(m);
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (SE_WG / 64) + (threadIdx.x >> 6);
+  const int tiles_x = (a.W + 7) >> 3;
+  const int px = ((tile % tiles_x) << 3) + (lane & 7);
+  const int py = ((tile / tiles_x) << 3) + (lane >> 3);
+  if (px >= a.W || py >= a.H) return;
+  const int pix = px + py * a.W;
+  f3 test, surfNorm;
+  if (sh.render) {
+    const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
+    const f3 org = {a.org[0], a.org[1], a.org[2]};
+    const RaySpan sp = se_ray_range(m, a, org, dir);
+    float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
+    BlkCache c = {-1, -1, -1, 0u};
+    RayCounters rc = {0ull, 0ull};
+    if (sp.tcmin > 0.f) se_cast_ray<OFUSION, false, DENSE>(m, a, fc, org, dir, sp.tcmin, sp.tmax, c, hx, hy, hz, hw, rc);
+    if (hw > 0) {
+      test = {hx, hy, hz};
+      const f3 g = se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, test), c);
+      surfNorm = f3_scale(a.grad_scale, g);
+      if (!OFUSION) surfNorm = f3_scale(-1.f, surfNorm);
+    } else {
+      test = {0.f, 0.f, 0.f};
+      surfNorm = {-2.f, 0.f, 0.f};
+    }
+  } else {
+    test = {vertex[3 * pix], vertex[3 * pix + 1], vertex[3 * pix + 2]};
+    surfNorm = {normal[3 * pix], normal[3 * pix + 1], normal[3 * pix + 2]};
+  }
+  unsigned char* o = out + 4 * (size_t)pix;
+  if (surfNorm.x != -2.f && sqrtf(f3_sqnorm(surfNorm)) > 0) {
+    const f3 diff = f3_normalized(f3_sub(test, {sh.light[0], sh.light[1], sh.light[2]}));
+    const f3 sn = f3_normalized(surfNorm);
+    const float dirv = fmaxf((sn.x * diff.x + sn.y * diff.y) + sn.z * diff.z, 0.f);
+    float col[3] = {dirv + sh.ambient[0], dirv + sh.ambient[1], dirv + sh.ambient[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      col[i] = std_max(col[i], 0.f);     // se::math::clamp on arrays: max then min (math_utils.h:111-116)
+      col[i] = std_min(col[i], 1.f);
+      col[i] *= 255.f;
+      o[i] = (unsigned char)col[i];
+    }
+    o[3] = 0;
+  } else {
+    o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0;
+  }
+}
+
+// gs2rgb (se_denseslam/include/se/commons.h:105-163), double arithmetic as in the reference
+__device__ __forceinline__ void se_gs2rgb(double h, unsigned char* rgbw) {
+  double r = 0, g = 0, b = 0;
+  const double v = 0.75, mm = 0.25, sv = 0.6667;
+  h *= 6.0;
+  const int sextant = (int)h;
+  const double fract = h - sextant;
+  const double vsf = v * sv * fract;
+  const double mid1 = mm + vsf, mid2 = v - vsf;
+  switch (sextant) {
+    case 0: r = v; g = mid1; b = mm; break;
+    case 1: r = mid2; g = v; b = mm; break;
+    case 2: r = mm; g = v; b = mid1; break;
+    case 3: r = mm; g = mid2; b = v; break;
+    case 4: r = mid1; g = mm; b = v; break;
+    case 5: r = v; g = mm; b = mid2; break;
+    default: r = 0; g = 0; b = 0; break;
+  }
+  rgbw[0] = (unsigned char)(r * 255); rgbw[1] = (unsigned char)(g * 255); rgbw[2] = (unsigned char)(b * 255); rgbw[3] = 0;
+}
+// renderDepthKernel (rendering.cpp:111-152)
+__global__ void k_render_depth(unsigned char* __restrict__ out, const float* __restrict__ depth, int n, float nearp, float farp) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n) return;
+  const float rangeScale = 1 / (farp - nearp);
+  unsigned char* o = out + 4 * (size_t)pos;
+  const float d0 = depth[pos];
+  if (d0 < nearp) { o[0] = 255; o[1] = 255; o[2] = 255; o[3] = 0; }
+  else if (d0 > farp) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
+  else { const float d = (d0 - nearp) * rangeScale; se_gs2rgb(d, o); }
 }

@@ -157,3 +157,21 @@ __global__ void k_track_reduce_final(float* __restrict__ out /*8*32*/, const flo
   }
   out[i] = row0;
 }
+
+// renderTrackKernel (rendering.cpp:154-213)
+__global__ void k_render_track(unsigned char* __restrict__ out, const TrackData* __restrict__ data, int n) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n) return;
+  unsigned char r, g, b;
+  switch (data[pos].result) {
+    case 1: r = 128; g = 128; b = 128; break;
+    case -1: r = 0; g = 0; b = 0; break;
+    case -2: r = 255; g = 0; b = 0; break;
+    case -3: r = 0; g = 255; b = 0; break;
+    case -4: r = 0; g = 0; b = 255; break;
+    case -5: r = 255; g = 255; b = 0; break;
+    default: r = 255; g = 128; b = 128; break;
+  }
+  unsigned char* o = out + 4 * (size_t)pos;
+  o[0] = r; o[1] = g; o[2] = b; o[3] = 0;
+}

@@ -55,6 +55,9 @@ EXPORTS = {
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "se_hip_track": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int32, _f32p]),
     "se_hip_download_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "se_hip_render_volume": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_uint32, C.c_uint32]),
+    "se_hip_render_depth": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se_hip_render_track": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "se_hip_download_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "se_hip_download_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -173,6 +176,22 @@ class DenseSLAMPipeline:
         it = C.c_int32()
         self._check(self.lib.se_hip_download_track(self._h, t.ctypes.data, red.ctypes.data, C.byref(it)))
         return t.reshape(self.H, self.W), red, it.value
+
+    # the render*() methods (DenseSLAMSystem.h:241-286): RGBW uint8 images
+    def renderVolume(self, view_pose, k, mu, largestep, frame=0, rate=1):
+        out = np.zeros((self.H, self.W, 4), np.uint8)
+        ran = self._check(self.lib.se_hip_render_volume(self._h, out.ctypes.data, _colmajor(view_pose), np.asarray(k, np.float32), mu, largestep, frame, rate))
+        return out if ran else None
+
+    def renderDepth(self):
+        out = np.zeros((self.H, self.W, 4), np.uint8)
+        self._check(self.lib.se_hip_render_depth(self._h, out.ctypes.data))
+        return out
+
+    def renderTrack(self):
+        out = np.zeros((self.H, self.W, 4), np.uint8)
+        self._check(self.lib.se_hip_render_track(self._h, out.ctypes.data))
+        return out
 
     # stage split used by the multi-GPU driver
     def alloc_scan(self, k, integration_rate: int, mu: float, frame: int) -> bool:
