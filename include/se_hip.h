@@ -139,6 +139,15 @@ int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float*
 /* internal nodes sorted by key: code[n] (key = code|level), side[n], x[n][8], y[n][8] (value_[8]) */
 int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, float* x, float* y);
 
+/* ---- "next" row f-4: Octree::save (se_core/include/se/octree.hpp:898-914, io/se_serialise.hpp:54-86),
+ *      written straight from the device map in the reference's byte layout:
+ *        int32 size, float dim, uint64 n_nodes, n_nodes x {uint64 code, int32 side, value_[8]},
+ *        uint64 n_blocks, n_blocks x {uint64 code, int32 coords[3], voxel_block_[512]}
+ *      with value_type = {float x, float y} (SDF) or {float x, 4 pad bytes, double y} (OFusion).
+ *      Nodes and blocks are written sorted by key (the reference writes its pool order, which is
+ *      nondeterministic under OpenMP). */
+int se_hip_save_map(se_hip_pipeline* p, const char* filename);
+
 /* ---- measurement (replaces TICK()/TOCK() + PerfStats, se_shared/timings.h:7-15) */
 #define SE_HIP_K_ALLOC_SCAN 0
 #define SE_HIP_K_ALLOC_COMMIT 1

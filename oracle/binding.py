@@ -103,6 +103,7 @@ def _declare(lib):
         "so_render_depth": (None, [c_u8p, c_f32p, i32, i32]),
         "so_render_track": (None, [c_u8p, C.c_void_p, i32, i32]),
         "so_pipe_render_volume": (None, [vp, c_u8p, c_f32p, c_f32p, c_f32p, f32, f32, c_f32p, c_f32p]),
+        "so_pipe_save": (i32, [vp, C.c_char_p]),
         "so_num_threads": (i32, []),
         "so_set_num_threads": (None, [i32]),
     }
@@ -127,7 +128,7 @@ def load(native: bool = False):
 
 
 SDF, OFUSION = 0, 1
-STAT_NAMES = ("probes", "keys_emitted", "swept", "nodes", "gets", "interps", "grads", "hits", "oob")
+STAT_NAMES = ("probes", "keys_emitted", "swept", "nodes", "gets", "interps", "grads", "hits", "oob", "truncated")
 
 
 class OraclePipeline:
@@ -196,6 +197,9 @@ class OraclePipeline:
                                        np.ascontiguousarray(normal, np.float32).reshape(-1))
         return out
 
+    def save(self, filename: str) -> bool:
+        return bool(self.lib.so_pipe_save(self.h, filename.encode()))
+
     def counts(self):
         nb, nn = C.c_int(), C.c_int()
         self.lib.so_pipe_counts(self.h, C.byref(nb), C.byref(nn))
@@ -222,7 +226,7 @@ class OraclePipeline:
         return code, side, x, y
 
     def stats(self) -> dict:
-        out = np.zeros(9, np.uint64)
+        out = np.zeros(10, np.uint64)
         self.lib.so_pipe_stats(self.h, out)
         return dict(zip(STAT_NAMES, (int(v) for v in out)))
 

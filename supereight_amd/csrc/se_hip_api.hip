@@ -998,6 +998,52 @@ int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, fl
   return SE_HIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------ map export
+int se_hip_save_map(se_hip_pipeline* p, const char* filename) {
+  if (int r = check(p)) return r;
+  if (!filename) return fail(SE_HIP_E_INVALID, "bad argument");
+  int32_t nb = 0, nn = 0;
+  if (int r = se_hip_counts(p, &nb, &nn)) return r;
+  std::vector<uint64_t> ncode(nn);
+  std::vector<uint32_t> nside(nn);
+  std::vector<float> nx((size_t)nn * 8), ny((size_t)nn * 8);
+  if (int r = se_hip_download_nodes(p, ncode.data(), nside.data(), nx.data(), ny.data())) return r;
+  std::vector<int32_t> coords((size_t)nb * 3);
+  std::vector<float> bx((size_t)nb * 512), by((size_t)nb * 512);
+  if (nb) if (int r = se_hip_download_blocks(p, coords.data(), bx.data(), by.data(), nullptr)) return r;
+  FILE* f = std::fopen(filename, "wb");
+  if (!f) return fail(SE_HIP_E_INVALID, std::string("cannot open ") + filename);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  auto put_value = [&](float x, float y) {
+    if (sdf) { const float v[2] = {x, y}; std::fwrite(v, 4, 2, f); }
+    else { const float xv = x; const uint32_t pad = 0; const double yv = y; std::fwrite(&xv, 4, 1, f); std::fwrite(&pad, 4, 1, f); std::fwrite(&yv, 8, 1, f); }
+  };
+  const int32_t size = p->map.size;
+  const float dim = p->map.dim;
+  std::fwrite(&size, 4, 1, f);
+  std::fwrite(&dim, 4, 1, f);
+  uint64_t n = (uint64_t)nn;
+  std::fwrite(&n, 8, 1, f);
+  for (int i = 0; i < nn; ++i) {
+    const int32_t side = (int32_t)nside[i];
+    std::fwrite(&ncode[i], 8, 1, f);
+    std::fwrite(&side, 4, 1, f);
+    for (int j = 0; j < 8; ++j) put_value(nx[(size_t)i * 8 + j], ny[(size_t)i * 8 + j]);
+  }
+  n = (uint64_t)nb;
+  std::fwrite(&n, 8, 1, f);
+  for (int i = 0; i < nb; ++i) {
+    const uint64_t code = se_make_key(coords[3 * i] >> 3, coords[3 * i + 1] >> 3, coords[3 * i + 2] >> 3, p->leaf_level, p->max_level);
+    std::fwrite(&code, 8, 1, f);
+    std::fwrite(&coords[3 * (size_t)i], 4, 3, f);
+    for (int j = 0; j < 512; ++j) put_value(bx[(size_t)i * 512 + j], by[(size_t)i * 512 + j]);
+  }
+  const bool okw = std::ferror(f) == 0;
+  std::fclose(f);
+  return okw ? SE_HIP_OK : fail(SE_HIP_E_INVALID, "write error");
+}
+
 // --------------------------------------------------------------------------------- measurement
 int se_hip_enable_timing(se_hip_pipeline* p, int32_t on) {
   if (int r = check(p)) return r;

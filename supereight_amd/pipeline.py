@@ -58,6 +58,7 @@ EXPORTS = {
     "se_hip_render_volume": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_uint32, C.c_uint32]),
     "se_hip_render_depth": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_render_track": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se_hip_save_map": (C.c_int, [C.c_void_p, C.c_char_p]),
     "se_hip_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "se_hip_download_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "se_hip_download_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -249,6 +250,10 @@ class DenseSLAMPipeline:
         y = np.zeros((nn, 8), np.float32)
         self._check(self.lib.se_hip_download_nodes(self._h, code.ctypes.data, side.ctypes.data, x.ctypes.data, y.ctypes.data))
         return code, side, x, y
+
+    def save(self, filename: str):
+        """Octree::save of the reference (octree.hpp:898-914): same byte layout, entries sorted by key."""
+        self._check(self.lib.se_hip_save_map(self._h, filename.encode()))
 
     # ------------------------------------------------------------------ measurement
     def enable_timing(self, on: bool = True):

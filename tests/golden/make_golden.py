@@ -29,7 +29,7 @@ def crc_rows(a):
 
 
 def main():
-    for name, field, mu in (("sdf", SDF, 0.1), ("ofusion", OFUSION, 0.04)):
+    for name, field, mu in (("sdf", SDF, 0.1), ("ofusion", OFUSION, 0.02)):
         s = SyntheticStream(W, H, DIM)
         o = OraclePipeline(field, N, DIM, W, H)
         depths, poses = [], []
@@ -40,6 +40,7 @@ def main():
             o.integrate(d, p, s.k, mu, f)
             ran, v, n = o.raycast(p, s.k, mu, f)
         assert ran
+        assert o.stats()["truncated"] == 0   # a saturated key buffer makes the reference itself nondeterministic
         c, x, y, a = o.blocks()
         code, side, nx, ny = o.nodes()
         out = os.path.join(ROOT, "tests", "golden", f"{name}_{W}x{H}_{N}.npz")
