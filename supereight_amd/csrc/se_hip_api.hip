@@ -644,6 +644,7 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   const M4 pose = from_colmajor(pose_cm);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   IntegArgs a{};
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) a.debug = std::atoi(ev);
   a.commit_occ = p->occ_commit_due ? 1 : 0;
   p->occ_commit_due = false;
   // Sophus::SE3f(pose_).inverse() (DenseSLAMSystem.cpp:237): (R^T, R^T * (t * -1)) taken from the matrix

@@ -319,6 +319,7 @@ struct IntegArgs {
   const float* bspline;    // OFusion: 1000-entry B-spline CDF table
   const float* logodds;    // OFusion: log2f(s/(1-s)) for every (Q1 index, Q2 index) pair, see se_hip_api.hip
   int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan first
+  int debug;               // diagnostic: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
 };
 
 #define SE_LO_DIM 1002  // 0..999 table entries, 1000 = "0" (t < -3), 1001 = "1" (t > 3)
@@ -334,12 +335,6 @@ __device__ __forceinline__ void se_sdf_apply(const IntegArgs& a, float depthSamp
     dirty = true;
   }
 }
-__device__ __forceinline__ void se_sdf_update(const IntegArgs& a, const float* __restrict__ depthmap, f3 pos, float px_, float py_,
-                                              float& vx, float& vy, bool& dirty) {
-  const int px = cvt_i32(px_), py = cvt_i32(py_);
-  se_sdf_apply(a, depthmap[px + a.W * py], pos, vx, vy, dirty);
-}
-
 // bspline_memoized index (se_denseslam/src/bfusion/mapping_impl.hpp:126-137)
 __device__ __forceinline__ int se_bspline_index(float t) {
   const float inverseRange = 1 / 6.f;
@@ -347,6 +342,45 @@ __device__ __forceinline__ int se_bspline_index(float t) {
   if (t > 3) return 1001;
   return 1000;
 }
+// Branch-free forms for the block sweep: every expression of the functor is evaluated for every lane
+// (results of lanes that the reference skips are discarded by the final selects), so that the 8
+// z-slices of a lane are 8 independent dependency chains the compiler can interleave -- the sweep is
+// bound by the latency of the IEEE division / square-root sequences, not by their count.
+__device__ __forceinline__ bool se_sdf_apply_nb(const IntegArgs& a, bool valid, float depthSample, f3 pos, float& vx, float& vy) {
+  const float diff = (depthSample - pos.z) * sqrtf(1 + sqf(pos.x / pos.z) + sqf(pos.y / pos.z));
+  const bool upd = valid && !(depthSample <= 0) && (diff > -a.mu);
+  const float sdf = fminf(1.f, diff / a.mu);
+  const float nx = clampf((vy * vx + sdf) / (vy + 1.f), -1.f, 1.f);
+  const float ny = fminf(vy + 1, a.maxweight);
+  vx = upd ? nx : vx;
+  vy = upd ? ny : vy;
+  return upd;
+}
+__device__ __forceinline__ bool se_bfusion_apply_nb(const IntegArgs& a, bool valid, float depthSample, f3 pos, float& vx, float& vy) {
+  const float diff = (pos.z - depthSample) * sqrtf(1 + sqf(pos.x / pos.z) + sqf(pos.y / pos.z));
+  const float sigma = clampf(a.mu * sqf(pos.z), 2 * a.voxel, 0.05f);
+  const float tt = diff / sigma;
+  const int i1 = se_bspline_index(tt), i2 = se_bspline_index(tt - 3);
+  const float q1 = a.bspline[i1 < 1000 ? i1 : 0], q2 = a.bspline[i2 < 1000 ? i2 : 0];
+  const float s1 = i1 < 1000 ? q1 : (i1 == 1001 ? 1.f : 0.f), s2 = i2 < 1000 ? q2 : (i2 == 1001 ? 1.f : 0.f);
+  const float sample = s1 - s2 * 0.5f;
+  const bool upd = valid && !(depthSample <= 0) && !(sample == 0.5f);
+  const float lo = a.logodds[i1 * SE_LO_DIM + i2];
+  const double delta_t = (double)a.timestamp - (double)vy;
+  const float dtf = (float)delta_t;
+  float fraction = 1.f / (1.f + (dtf / 4.f));
+  fraction = std_max(0.5f, fraction);
+  const float nx = clampf(vx * fraction + lo, -1000.f, 1000.f);
+  vx = upd ? nx : vx;
+  vy = upd ? a.timestamp : vy;
+  return upd;
+}
+__device__ __forceinline__ void se_sdf_update(const IntegArgs& a, const float* __restrict__ depthmap, f3 pos, float px_, float py_,
+                                              float& vx, float& vy, bool& dirty) {
+  const int px = cvt_i32(px_), py = cvt_i32(py_);
+  se_sdf_apply(a, depthmap[px + a.W * py], pos, vx, vy, dirty);
+}
+
 // bfusion_update::operator() (se_denseslam/src/bfusion/mapping_impl.hpp:157-191)
 __device__ __forceinline__ void se_bfusion_apply(const IntegArgs& a, float depthSample, f3 pos, float& vx, float& vy, bool& dirty) {
   if (depthSample <= 0) return;
@@ -453,28 +487,52 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     float* px = m.vx + (size_t)slot * 512 + lane;
     float* py = m.vy + (size_t)slot * 512 + lane;
     float vx[8], vy[8];
+    if (a.debug == 2) {
 #pragma unroll
-    for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
+      for (int zi = 0; zi < 8; ++zi) { vx[zi] = 1.f; vy[zi] = (float)zi; }
+    } else {
+#pragma unroll
+      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
+    }
+    if (a.debug == 1) {
+#pragma unroll
+      for (int zi = 0; zi < 8; ++zi) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
+      continue;
+    }
     bool visible = false;
     const int y = by + ly;
+    // update_block (projective_functor.hpp:73-111) in stages over the 8 z-slices of the lane, without
+    // branches: each stage is 8 independent copies of the same short dependency chain.
+    f3 pos[8];
+    int pidx[8];
+    bool valid[8];
+    float ds[8];
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
       const int z = bz + zi;
-      // update_block: projective_functor.hpp:73-111
       const f3 start = f3_add(m3_mul(a.R, {bx * a.voxel, y * a.voxel, z * a.voxel}), {a.t[0], a.t[1], a.t[2]});
       const f3 camerastart = m3_mul(a.K3, start);
       const f3 camera_voxel = f3_add(camerastart, f3_scale(fx, {a.cdelta[0], a.cdelta[1], a.cdelta[2]}));
-      const f3 pos = f3_add(start, f3_scale(fx, {a.delta[0], a.delta[1], a.delta[2]}));
-      if (pos.z < 0.0001f) continue;
+      pos[zi] = f3_add(start, f3_scale(fx, {a.delta[0], a.delta[1], a.delta[2]}));
       const float inverse_depth = 1.f / camera_voxel.z;
       const float pixx = camera_voxel.x * inverse_depth + 0.5f;
       const float pixy = camera_voxel.y * inverse_depth + 0.5f;
-      if (pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f) continue;
-      visible = true;
-      bool dirty = false;
-      if (OFUSION) se_bfusion_update(a, depthmap, pos, pixx, pixy, vx[zi], vy[zi], dirty);
-      else se_sdf_update(a, depthmap, pos, pixx, pixy, vx[zi], vy[zi], dirty);
-      if (dirty) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
+      valid[zi] = !(pos[zi].z < 0.0001f) && !(pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f);
+      visible = visible || valid[zi];
+      pidx[zi] = valid[zi] ? cvt_i32(pixx) + a.W * cvt_i32(pixy) : 0;   // sdf_update / bfusion_update: pixel.cast<int>()
+    }
+#pragma unroll
+    for (int zi = 0; zi < 8; ++zi) ds[zi] = depthmap[pidx[zi]];
+    bool upd[8];
+#pragma unroll
+    for (int zi = 0; zi < 8; ++zi)
+      upd[zi] = OFUSION ? se_bfusion_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]) : se_sdf_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
+    // a voxel the functor left alone is written back unchanged only if a neighbour in the same 256-byte
+    // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
+#pragma unroll
+    for (int zi = 0; zi < 8; ++zi) {
+      if (a.debug == 2) { if (vx[zi] == 12345.f) px[zi * 64] = vx[zi]; continue; }   // diagnostic: keep the arithmetic alive
+      if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
