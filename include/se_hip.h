@@ -65,6 +65,11 @@ const char* se_hip_last_error(void);
 int se_hip_sync(se_hip_pipeline* p);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the handle's own. */
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
+/* The stream the allocation scan (se_hip_alloc_scan) is launched on when it overlaps the previous
+ * frame's raycast (dense replicas).  The multi-GPU driver passes the stream its
+ * all-gather of the key lists is ordered on, so that scan + exchange of frame f+1 hide behind the
+ * raycast of frame f.  NULL = a stream owned by the handle (the default). */
+int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
 
 /* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by
  * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141). */

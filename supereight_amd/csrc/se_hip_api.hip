@@ -67,8 +67,10 @@ struct se_hip_pipeline {
   // side stream: the allocation scan (and the depth upload feeding it) of frame f+1 runs here,
   // concurrently with the raycast of frame f on `stream` (dense, unsharded replicas only)
   hipStream_t side = nullptr;
+  bool own_side = false;       // false after se_hip_set_scan_stream handed one in
   hipEvent_t ev_sweep = nullptr, ev_scan = nullptr;
   bool overlap = false;
+  bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool upload_on_side = false; // the current depth image was uploaded on `side`
   bool occ_commit_due = false; // the next sweep kernel must publish the scan's occupancy bits
@@ -305,21 +307,23 @@ hipStream_t upload_stream(se_hip_pipeline* p) {
 // occupancy bits of what it inserted (the scan left occ[] alone because the previous frame's raycast
 // may still have been walking it) and apply OFusion's keys[0] quirk.
 int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
-  if (!p->scan_pending) {
-    if (p->upload_on_side) { hipEventRecord(p->ev_scan, p->side); hipStreamWaitEvent(p->stream, p->ev_scan, 0); p->upload_on_side = false; }
-    return SE_HIP_OK;
+  if (p->scan_pending) {
+    p->scan_pending = false;
+    p->upload_on_side = false;
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0));
+    p->occ_commit_due = true;
+    // keys[0] quirk: a row-sharded replica applies it in se_hip_alloc_commit, over every rank's list
+    if (p->cfg.field_type == SE_HIP_FIELD_OFUSION && !p->sharded)
+      if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r;
+  } else if (p->upload_on_side) {
+    hipEventRecord(p->ev_scan, p->side); hipStreamWaitEvent(p->stream, p->ev_scan, 0); p->upload_on_side = false;
   }
-  p->scan_pending = false;
-  p->upload_on_side = false;
-  HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0));
-  if (fold_into_sweep) {
-    p->occ_commit_due = true;   // the sweep kernel launched next publishes the bits itself
-  } else {
+  // the sweep kernel publishes the bits itself when it is the next launch (fold_into_sweep)
+  if (p->occ_commit_due && !fold_into_sweep) {
+    p->occ_commit_due = false;
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
     hipLaunchKernelGGL(k_occ_commit, dim3(64), dim3(SE_WG), 0, p->stream, p->map);
   }
-  if (p->cfg.field_type == SE_HIP_FIELD_OFUSION)
-    if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r;
   return SE_HIP_OK;
 }
 
@@ -404,10 +408,11 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->own_stream = true;
   e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
   if (e != hipSuccess) return bail(e, "hipStreamCreate");
+  p->own_side = true;
   hipEventCreateWithFlags(&p->ev_sweep, hipEventDisableTiming);
   hipEventCreateWithFlags(&p->ev_scan, hipEventDisableTiming);
-  const bool sharded = (p->row_begin != 0 || p->row_end != cfg->height);
-  p->overlap = dense && !sharded && !std::getenv("SE_HIP_NO_OVERLAP");
+  p->sharded = (p->row_begin != 0 || p->row_end != cfg->height);
+  p->overlap = dense && !std::getenv("SE_HIP_NO_OVERLAP");
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
   ALLOC(m.vx, slots * 512 * sizeof(float));
@@ -484,7 +489,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   if (p->reduce_out) hipFree(p->reduce_out);
   if (p->reduce_host) hipHostFree(p->reduce_host);
   if (p->ctr_host) hipHostFree(p->ctr_host);
-  if (p->side) hipStreamDestroy(p->side);
+  if (p->own_side && p->side) hipStreamDestroy(p->side);
   if (p->ev_sweep) hipEventDestroy(p->ev_sweep);
   if (p->ev_scan) hipEventDestroy(p->ev_scan);
   if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
@@ -506,6 +511,19 @@ int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
   if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
   p->stream = (hipStream_t)hip_stream;
   p->own_stream = false;
+  return SE_HIP_OK;
+}
+
+int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
+  if (int r = check(p)) return r;
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  drain_timings(p);
+  if (p->own_side && p->side) hipStreamDestroy(p->side);
+  p->side = nullptr; p->own_side = false;
+  if (hip_stream) { p->side = (hipStream_t)hip_stream; return SE_HIP_OK; }
+  HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+  p->own_side = true;
   return SE_HIP_OK;
 }
 
@@ -624,7 +642,7 @@ int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
-  if (int r = join_scan(p)) return r;
+  if (int r = join_scan(p, true)) return r;   // the sweep that follows publishes the scan's occupancy bits
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
     hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, (const unsigned long long*)device_lists, nlists, (long long)stride_words);

@@ -61,10 +61,17 @@ def merged_keys(gathered, world: int) -> np.ndarray:
 
 
 class ShardedPipeline:
-    """Row-sharded DenseSLAMPipeline replica of one rank."""
+    """Row-sharded DenseSLAMPipeline replica of one rank.
+
+    Stream plan (R > 1): the allocation scan of frame f+1 and the all-gather of its key lists are
+    ordered on an exchange stream that only waits for the sweep of frame f, so both hide behind the
+    raycast of frame f, which runs on the main stream; the main stream joins the exchange stream
+    before it inserts the other ranks' keys.  The host never synchronises inside ``frame``.
+    """
 
     def __init__(self, input_size, volume_resolution, volume_dimension, field_type, rank, world, device,
-                 small_words: int = 1 << 16, big_words: int = 0, max_blocks: int = 0, group=None):
+                 small_words: int = 0, big_words: int = 0, max_blocks: int = 0, group=None,
+                 exchange_always: bool = False):
         import torch
         from .pipeline import DenseSLAMPipeline
         self.torch = torch
@@ -76,30 +83,57 @@ class ShardedPipeline:
         dev = torch.device("cuda", device)
         _, cap = self.p.new_keys_device()
         self.big_words = int(big_words) if big_words else int(min(cap, 1 << 22))
+        # steady state: the surface newly in view per frame; grows with the square of the resolution
+        if not small_words:
+            small_words = 16384 * max(1, int(volume_resolution) // 512) ** 2
         self.small_words = int(min(small_words, self.big_words))
         self.send = torch.zeros(self.big_words, dtype=torch.int64, device=dev)
         self.recv = torch.zeros(world * self.big_words, dtype=torch.int64, device=dev)
-        # every launch of the replica and the collective share torch's current stream
-        self.p.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self._views = {w: (self.send[:w], self.recv[: world * w]) for w in {self.big_words, self.small_words}}
+        self._words = 0
+        self.gloo = False
+        # exchange_always: run the exchange + commit steps with a single rank too (test hook: the own list
+        # is committed a second time, which changes nothing)
+        self.exchange = world > 1 or exchange_always
+        self.main = torch.cuda.current_stream(dev)
+        self.xs = None
+        self._pg = None
+        if self.exchange:
+            import torch.distributed as dist
+            self.gloo = dist.get_backend(group) == "gloo"
+            # scan + collective are ordered on the stream that is current now (the collective is issued
+            # without a stream context switch per frame); the sweep and the raycast get a stream of their own
+            self.xs = torch.cuda.current_stream(dev)
+            self.main = torch.cuda.Stream(dev)
+            self.p.set_scan_stream(self.xs.cuda_stream)
+            pg = group if group is not None else dist.group.WORLD
+            self._pg = pg if (not self.gloo and hasattr(pg, "_allgather_base")) else None
+        self.p.set_stream(self.main.cuda_stream)
 
     def frame(self, depth_ptr: int, pose, k, mu: float, frame: int, integration_rate: int = 1):
         p = self.p
         p.set_depth_device(depth_ptr)
         p.setPose(pose)
         words = self.big_words if frame <= BIG_FRAMES else self.small_words
-        p.set_new_keys_buffer(self.send.data_ptr(), words, keepalive=self.send)
+        if words != self._words:
+            p.set_new_keys_buffer(self.send.data_ptr(), words, keepalive=self.send)
+            self._words = words
         ran = p.alloc_scan(k, integration_rate, mu, frame)
         if ran:
-            if self.world > 1:
-                import torch.distributed as dist
-                recv = self.recv[: self.world * words]
-                if dist.get_backend(self.group) == "gloo":
+            if self.exchange:
+                send, recv = self._views[words]
+                if self.gloo:
                     # dry-run transport (several ranks sharing one GPU, no RCCL): stage through the host
-                    host = exchange_key_lists(self.send[:words].cpu(), self.world, self.group)
+                    host = exchange_key_lists(send.cpu(), self.world, self.group)   # .cpu(): ordered on xs, blocks the host
                     recv.copy_(host)
-                    self.torch.cuda.synchronize()
+                    self.main.wait_stream(self.xs)
                 else:
-                    dist.all_gather_into_tensor(recv, self.send[:words], group=self.group)
+                    if self._pg is not None:
+                        self._pg._allgather_base(recv, send).wait()   # wait() = the issuing stream waits, not the host
+                    else:
+                        import torch.distributed as dist
+                        dist.all_gather_into_tensor(recv, send, group=self.group)
+                    self.main.wait_stream(self.xs)
                 p.alloc_commit(recv.data_ptr(), self.world, words)
             p.integrate_sweep(k, integration_rate, mu, frame)
         p.raycasting(k, mu, frame)

@@ -41,6 +41,7 @@ EXPORTS = {
     "se_hip_last_error": (C.c_char_p, []),
     "se_hip_sync": (C.c_int, [C.c_void_p]),
     "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_upload_depth": (C.c_int, [C.c_void_p, _f32p]),
     "se_hip_upload_depth_mm": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     "se_hip_set_depth_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -104,8 +105,26 @@ class DenseSLAMPipeline:
         self._h = None
         self._check(self.lib.se_hip_create(C.byref(cfg), C.byref(h)))
         self._h = h
-        self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else np.asarray(init_pose, np.float32).copy()
+        self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else init_pose
         self._keepalive = None
+
+    # pose_ (camera -> world, row-major 4x4) and its column-major copy for the C ABI; assign, do not
+    # modify in place
+    @property
+    def pose_(self):
+        return self._pose
+
+    @pose_.setter
+    def pose_(self, m):
+        self._pose = np.array(m, dtype=np.float32).reshape(4, 4)
+        self._pose_cm = np.ascontiguousarray(self._pose.T).reshape(16)
+
+    @staticmethod
+    def _k(k):
+        """float32[4] intrinsics (fx, fy, cx, cy) for the C ABI; no copy if it already is one."""
+        if type(k) is np.ndarray and k.dtype == np.float32 and k.size == 4 and k.flags.c_contiguous:
+            return k
+        return np.ascontiguousarray(k, dtype=np.float32).reshape(4)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, status: int) -> int:
@@ -130,10 +149,13 @@ class DenseSLAMPipeline:
     def set_stream(self, hip_stream_ptr: int):
         self._check(self.lib.se_hip_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 
+    def set_scan_stream(self, hip_stream_ptr: int):
+        self._check(self.lib.se_hip_set_scan_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
     # ------------------------------------------------------------------ reference-shaped API
     def setPose(self, pose):
         """DenseSLAMSystem::setPose semantics minus the init-pose offset: pose is camera->world."""
-        self.pose_ = np.asarray(pose, np.float32).reshape(4, 4).copy()
+        self.pose_ = pose
 
     def getPose(self):
         return self.pose_.copy()
@@ -155,11 +177,11 @@ class DenseSLAMPipeline:
         self._check(self.lib.se_hip_set_depth_device(self._h, C.c_void_p(ptr)))
 
     def integration(self, k, integration_rate: int, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_integrate(self._h, _colmajor(self.pose_), np.asarray(k, np.float32),
+        return bool(self._check(self.lib.se_hip_integrate(self._h, self._pose_cm, self._k(k),
                                                           integration_rate, mu, frame)))
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_raycast(self._h, _colmajor(self.pose_), np.asarray(k, np.float32), mu, frame)))
+        return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm, self._k(k), mu, frame)))
 
     TRACK_DTYPE = np.dtype([("result", np.int32), ("error", np.float32), ("J", np.float32, 6)])
 
@@ -196,7 +218,7 @@ class DenseSLAMPipeline:
 
     # stage split used by the multi-GPU driver
     def alloc_scan(self, k, integration_rate: int, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_alloc_scan(self._h, _colmajor(self.pose_), np.asarray(k, np.float32),
+        return bool(self._check(self.lib.se_hip_alloc_scan(self._h, self._pose_cm, self._k(k),
                                                            integration_rate, mu, frame)))
 
     def new_keys_device(self):
@@ -212,7 +234,7 @@ class DenseSLAMPipeline:
         self._check(self.lib.se_hip_alloc_commit(self._h, C.c_void_p(lists_ptr), nlists, stride_words))
 
     def integrate_sweep(self, k, integration_rate: int, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, _colmajor(self.pose_), np.asarray(k, np.float32),
+        return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, self._pose_cm, self._k(k),
                                                                 integration_rate, mu, frame)))
 
     # ------------------------------------------------------------------ outputs

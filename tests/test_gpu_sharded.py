@@ -62,3 +62,41 @@ def test_sharded_replicas_equal_single(field, mu, R):
         p.close()
     assert (vs.view(np.uint32) == v.view(np.uint32)).all() and (ns.view(np.uint32) == n.view(np.uint32)).all()
     single.close()
+
+
+def test_sharded_pipeline_stream_plan_single_rank_rccl():
+    """ShardedPipeline with a one-rank RCCL group: the exchange stream, the all-gather call and the
+    commit of the gathered list run exactly as with R > 1 (the own list is committed again, a no-op);
+    the result must equal the plain pipeline's."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from supereight_amd.multi_gpu import ShardedPipeline
+    W, H, N, dim, mu, frames = 160, 120, 256, 2.4, 0.1, 8
+    stream = SyntheticStream(W, H, dim)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        single = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+        sp = ShardedPipeline((W, H), N, dim, SDF, 0, 1, 0, exchange_always=True)
+        depth = torch.from_numpy(np.stack([stream.depth(f) for f in range(frames)])).cuda()
+        for f in range(frames):
+            single.set_depth_device(depth[f].data_ptr()); single.setPose(stream.pose(f))
+            single.integration(stream.k, 1, mu, f)
+            single.raycasting(stream.k, mu, f)
+            sp.frame(depth[f].data_ptr(), stream.pose(f), stream.k, mu, f)
+        torch.cuda.synchronize()
+        c, x, y, a = single.blocks()
+        rc, rx, ry, ra = sp.p.blocks()
+        assert len(c) > 500 and rc.shape == c.shape and (rc == c).all() and (ra == a).all()
+        assert (rx.view(np.uint32) == x.view(np.uint32)).all() and (ry.view(np.uint32) == y.view(np.uint32)).all()
+        v, n = single.vertex_normal()
+        rv, rn = sp.p.vertex_normal()
+        assert (rv.view(np.uint32) == v.view(np.uint32)).all() and (rn.view(np.uint32) == n.view(np.uint32)).all()
+        sp.close(); single.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
