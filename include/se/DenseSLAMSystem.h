@@ -7,7 +7,7 @@
  *
  * What is kept (same names, argument meaning and "did the stage run" return values):
  *   the two constructors, preprocessing() (mm -> metres, preprocessing.cpp:161-188, fused into the
- *   upload; the bilateral filter is outside the path this library implements), integration(),
+ *   upload; the optional bilateral filter runs on the device in front of tracking()), integration(),
  *   tracking(), raycasting(), setPose()/getPose()/getPosition()/getInitPos(), getIntegrated(), getTracked(),
  *   getModelDimensions()/getModelResolution()/getComputationResolution(), renderVolume()/renderTrack()/
  *   renderDepth(), setViewPose()/getViewPose(), synchroniseDevices().
@@ -123,8 +123,8 @@ class DenseSLAMSystem {
 
   /* DenseSLAMSystem.h:147 / DenseSLAMSystem.cpp:128-141 */
   bool preprocessing(const unsigned short* inputDepth, const Eigen::Vector2i& inputSize, const bool filterInput) {
-    if (filterInput) std::cerr << "DenseSLAMSystem: bilateral filtering is not part of the HIP path; using unfiltered depth" << std::endl;
-    return ok(se_hip_upload_depth_mm(h_, inputDepth, inputSize.x(), inputSize.y()));
+    // bilateralFilterKernel feeds only the tracking pyramid (scaled_depth_[0]); it runs inside se_hip_track
+    return ok(se_hip_filter_depth(h_, filterInput ? 1 : 0)) && ok(se_hip_upload_depth_mm(h_, inputDepth, inputSize.x(), inputSize.y()));
   }
   /* the reference's float_depth_ handed over directly (metres) */
   bool preprocessing(const float* depthMetres) { return ok(se_hip_upload_depth(h_, depthMetres)); }

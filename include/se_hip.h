@@ -121,6 +121,12 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, f
  *      level, finest first (default {10, 5, 4}).  Returns 1 = tracked, 0 = gated off or rejected. */
 int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame,
                  const int32_t* pyramid, int32_t n_levels, float pose_inout[16]);
+/* preprocessing(..., filterInput) (DenseSLAMSystem.cpp:128-141): when on, se_hip_track works on
+ * bilateralFilterKernel(float_depth_) (preprocessing.cpp:41-89, gaussian_ of DenseSLAMSystem.cpp:111-118)
+ * instead of float_depth_ itself; integration always uses the unfiltered image, as in the reference. */
+int se_hip_filter_depth(se_hip_pipeline* p, int32_t on);
+/* scaled_depth_[level] as built by the last se_hip_track ((width >> level) x (height >> level) floats). */
+int se_hip_download_scaled_depth(se_hip_pipeline* p, int32_t level, float* host_out);
 /* tracking_result_ (TrackData {int result; float error; float J[6];} per pixel, commons.h:249-253) and
  * row 0 of reduction_output_ (32 floats) of the last ICP iteration; iterations run in the last call. */
 int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_reduce32[32], int32_t* iterations);

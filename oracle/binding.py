@@ -94,6 +94,7 @@ def _declare(lib):
         "so_pipe_get_nodes": (None, [vp, c_u64p, c_u32p, c_f32p, c_f32p]),
         "so_pipe_stats": (None, [vp, c_u64p]),
         "so_pipe_timings": (None, [vp, c_f64p]),
+        "so_bilateral_filter": (None, [c_f32p, c_f32p, i32, i32]),
         "so_half_sample": (None, [c_f32p, i32, i32, c_f32p, i32, f32, i32]),
         "so_depth2vertex": (None, [c_f32p, c_f32p, i32, i32, c_f32p]),
         "so_vertex2normal": (None, [c_f32p, c_f32p, i32, i32, i32]),
@@ -237,6 +238,15 @@ class OraclePipeline:
 
 
 TRACK_DTYPE = np.dtype([("result", np.int32), ("error", np.float32), ("J", np.float32, 6)])
+
+
+def oracle_bilateral_filter(depth):
+    """bilateralFilterKernel of preprocessing(..., filterInput=true): scaled_depth_[0] from float_depth_."""
+    lib = load()
+    H, W = depth.shape
+    out = np.empty((H, W), np.float32)
+    lib.so_bilateral_filter(out.reshape(-1), np.ascontiguousarray(depth, np.float32).reshape(-1), W, H)
+    return out
 
 
 def oracle_tracking(depth, k, pose, raycast_pose, ref_vertex, ref_normal, icp_threshold=1e-5, pyramid=(10, 5, 4)):

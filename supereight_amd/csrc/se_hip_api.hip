@@ -73,6 +73,8 @@ struct se_hip_pipeline {
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool upload_on_side = false; // the current depth image was uploaded on `side`
+  const float* scaled0 = nullptr;   // scaled_depth_[0] of the last se_hip_track
+  bool filter_input = false;   // preprocessing(..., filterInput): tracking sees the bilateral-filtered depth
   bool occ_commit_due = false; // the next sweep kernel must publish the scan's occupancy bits
   // tracking
   float raycast_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // column-major, pose of the last raycast
@@ -783,7 +785,7 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     p->pyr_depth.resize(n_levels, nullptr); p->pyr_vertex.resize(n_levels, nullptr); p->pyr_normal.resize(n_levels, nullptr);
     for (int i = 0; i < n_levels; ++i) {
       const size_t n = (size_t)(W >> i) * (H >> i);
-      if (i > 0 && !p->pyr_depth[i]) HIP_TRY(hipMalloc((void**)&p->pyr_depth[i], n * sizeof(float)));
+      if (!p->pyr_depth[i]) HIP_TRY(hipMalloc((void**)&p->pyr_depth[i], n * sizeof(float)));
       if (!p->pyr_vertex[i]) { HIP_TRY(hipMalloc((void**)&p->pyr_vertex[i], n * 3 * sizeof(float))); HIP_TRY(hipMemsetAsync(p->pyr_vertex[i], 0, n * 3 * sizeof(float), s)); }
       if (!p->pyr_normal[i]) { HIP_TRY(hipMalloc((void**)&p->pyr_normal[i], n * 3 * sizeof(float))); HIP_TRY(hipMemsetAsync(p->pyr_normal[i], 0, n * 3 * sizeof(float), s)); }
     }
@@ -797,6 +799,13 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   }
   // pyramid (DenseSLAMSystem.cpp:149-163): scaled_depth_[0] is the current depth image
   const float* d0 = p->depth;
+  if (p->filter_input) {   // DenseSLAMSystem.cpp:132-135; gaussian_: DenseSLAMSystem.cpp:111-118
+    Gauss5 G;
+    for (unsigned int i = 0; i < 5; i++) { const int x = (int)i - 2; G.g[i] = expf(-(x * x) / (2 * 4.0f * 4.0f)); }
+    hipLaunchKernelGGL(k_bilateral_filter, dim3((W + 255) / 256, H), dim3(256), 0, s, p->pyr_depth[0], d0, W, H, G, 0.1f);
+    d0 = p->pyr_depth[0];
+  }
+  p->scaled0 = d0;
   for (int i = 1; i < n_levels; ++i) {
     const int w = W >> i, h = H >> i;
     const float* src = i == 1 ? d0 : p->pyr_depth[i - 1];
@@ -847,6 +856,22 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   if ((std::sqrt(v[0] / v[28]) > 2e-2) || (v[28] / (W * H) < 0.15f)) { pose = old_pose; tracked = false; }
   for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) pose_cm[c * 4 + r] = pose.m[r][c];
   return tracked ? 1 : 0;
+}
+
+int se_hip_filter_depth(se_hip_pipeline* p, int32_t on) {
+  if (int r = check(p)) return r;
+  p->filter_input = on != 0;
+  return SE_HIP_OK;
+}
+
+int se_hip_download_scaled_depth(se_hip_pipeline* p, int32_t level, float* host_out) {
+  if (int r = check(p)) return r;
+  if (!host_out || level < 0 || level >= (int)p->pyr_depth.size() || !p->scaled0) return fail(SE_HIP_E_INVALID, "no such pyramid level (se_hip_track builds it)");
+  const float* src = level == 0 ? p->scaled0 : p->pyr_depth[level];
+  const size_t n = (size_t)(p->cfg.width >> level) * (p->cfg.height >> level);
+  HIP_TRY(hipMemcpyAsync(host_out, src, n * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return SE_HIP_OK;
 }
 
 int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_reduce32[32], int32_t* iterations) {

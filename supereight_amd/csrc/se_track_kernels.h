@@ -10,6 +10,34 @@
 
 struct TrackData { int result; float error; float J[6]; };   // se_denseslam/include/se/commons.h:249-253
 
+// bilateralFilterKernel (preprocessing.cpp:41-89), radius 2.  The reference's expf is its C library's;
+// here it is the correctly rounded one (double exp, rounded once), which differs from a given libm
+// in the last bit of a small fraction of arguments -- the one stage with a stated tolerance.
+struct Gauss5 { float g[5]; };
+__global__ void k_bilateral_filter(float* __restrict__ out, const float* __restrict__ in, int width, int height, Gauss5 G, float e_d) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  const int pos = x + y * width;
+  const float center = in[pos];
+  if (center == 0) { out[pos] = 0; return; }
+  const float e_d_squared_2 = e_d * e_d * 2;
+  float sum = 0.0f, t = 0.0f;
+#pragma unroll
+  for (int i = -2; i <= 2; ++i)
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+      const int ux = min(max(x + i, 0), width - 1), uy = min(max(y + j, 0), height - 1);
+      const float curPix = in[ux + uy * width];
+      if (curPix > 0) {
+        const float mod = (curPix - center) * (curPix - center);
+        const float factor = G.g[i + 2] * G.g[j + 2] * (float)exp((double)(-mod / e_d_squared_2));
+        t += factor * curPix;
+        sum += factor;
+      }
+    }
+  out[pos] = t / sum;
+}
+
 // halfSampleRobustImageKernel (preprocessing.cpp:190-226)
 __global__ void k_half_sample(float* __restrict__ out, int ow, int oh, const float* __restrict__ in, int iw, float e_d, int r) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;

@@ -55,6 +55,8 @@ EXPORTS = {
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "se_hip_track": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int32, _f32p]),
+    "se_hip_filter_depth": (C.c_int, [C.c_void_p, C.c_int32]),
+    "se_hip_download_scaled_depth": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "se_hip_download_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "se_hip_render_volume": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_uint32, C.c_uint32]),
     "se_hip_render_depth": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -182,6 +184,15 @@ class DenseSLAMPipeline:
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm, self._k(k), mu, frame)))
+
+    def filter_depth(self, on: bool = True):
+        """preprocessing(..., filterInput): tracking works on the bilateral-filtered depth image."""
+        self._check(self.lib.se_hip_filter_depth(self._h, int(on)))
+
+    def scaled_depth(self, level: int = 0) -> np.ndarray:
+        out = np.empty((self.H >> level, self.W >> level), np.float32)
+        self._check(self.lib.se_hip_download_scaled_depth(self._h, level, out.ctypes.data))
+        return out
 
     TRACK_DTYPE = np.dtype([("result", np.int32), ("error", np.float32), ("J", np.float32, 6)])
 

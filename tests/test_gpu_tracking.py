@@ -75,3 +75,49 @@ def test_tracking_gate_and_rejection():
     assert p.tracking(s.k, 1e-5, 1, 4) is False
     assert (p.getPose() == far).all()
     p.close()
+
+
+def test_bilateral_filter_in_front_of_tracking():
+    """preprocessing(..., filterInput=true): bilateralFilterKernel feeds the tracking pyramid.  The filter
+    calls expf, whose last bit belongs to the C library the reference happens to be linked with; the HIP
+    kernel uses the correctly rounded value.  Stated tolerance: filtered depth within 1e-6 relative (zeros
+    exactly preserved), tracked pose within 1e-5 of the oracle's."""
+    from oracle.binding import oracle_bilateral_filter
+    W, H, N, dim, mu = 320, 240, 256, 4.8, 0.1
+    s = SyntheticStream(W, H, dim)
+    cpu = OraclePipeline(SDF, N, dim, W, H)
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+    v_c = n_c = rp_c = None
+    for f in range(4):
+        depth, pose = s.depth(f), s.pose(f)
+        gpu.set_depth(depth); gpu.setPose(pose)
+        cpu.integrate(depth, pose, s.k, mu, f); gpu.integration(s.k, 1, mu, f)
+        ran, vv, nn = cpu.raycast(pose, s.k, mu, f); gpu.raycasting(s.k, mu, f)
+        if ran:
+            v_c, n_c, rp_c = vv, nn, pose.copy()
+    depth = s.depth(4)
+    gpu.set_depth(depth)
+    gpu.filter_depth(True)
+    filt_c = oracle_bilateral_filter(depth)
+    ok_c, pose_c, track_c, red_c, it_c = oracle_tracking(filt_c, s.k, s.pose(3), rp_c, v_c, n_c, 1e-5, (10, 5, 4))
+    ok_g = gpu.tracking(s.k, 1e-5, 1, 4, (10, 5, 4))
+    filt_g = gpu.scaled_depth(0)
+    assert ((filt_g == 0) == (depth == 0)).all() and ((filt_c == 0) == (depth == 0)).all()
+    assert np.abs(filt_c - depth).max() > 1e-4          # the filter does something on the quantised depth
+    nz = depth != 0
+    rel = np.abs(filt_g[nz] - filt_c[nz]) / filt_c[nz]
+    same = (filt_g.view(np.uint32) == filt_c.view(np.uint32)).mean()
+    print(f"bilateral filter: {100 * same:.3f} % of pixels bit-identical, max relative difference {rel.max():.2e}")
+    assert rel.max() < 1e-6 and same > 0.9
+    assert ok_g == ok_c and ok_c
+    assert np.abs(gpu.getPose() - pose_c).max() < 1e-5
+    track_g, red_g, it_g = gpu.track_data()
+    assert (track_g["result"] == track_c["result"]).mean() > 0.999
+    # switched off again: bit-exact path
+    gpu.filter_depth(False)
+    gpu.setPose(s.pose(3))
+    ok_c2, pose_c2, *_ = oracle_tracking(depth, s.k, s.pose(3), rp_c, v_c, n_c, 1e-5, (10, 5, 4))
+    gpu.tracking(s.k, 1e-5, 1, 4, (10, 5, 4))
+    assert (gpu.getPose().view(np.uint32) == pose_c2.view(np.uint32)).all()
+    assert (gpu.scaled_depth(0).view(np.uint32) == depth.view(np.uint32)).all()
+    cpu.close(); gpu.close()
