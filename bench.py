@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--dim", type=float, default=4.8)
     ap.add_argument("--mu", type=float, default=0.1)
     ap.add_argument("--field", choices=["sdf", "ofusion"], default="sdf")
+    ap.add_argument("--icl-like", action="store_true",
+                    help="the analytic stream seen through the ICL-NUIM camera (-k 481.2,-480,320,240: negative fy), BASELINE.json configs 1 / 3 without the data set")
+    ap.add_argument("--raw", type=str, default=os.environ.get("SE_ICL_RAW", ""), help="SLAMBench .raw depth stream (e.g. ICL-NUIM living_room_traj2_loop) instead of the synthetic one")
+    ap.add_argument("--traj", type=str, default=os.environ.get("SE_ICL_TRAJ", ""), help="ground-truth trajectory for --raw (... tx ty tz qx qy qz qw per line)")
+    ap.add_argument("--init-pose", type=str, default="0.34,0.5,0.24", help="initial position as fractions of the volume edge (README.md:80 of the reference: -p 0.34,0.5,0.24)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--event-stride", type=int, default=10,
                     help="record per-kernel HIP events on every n-th timed frame (1 = every frame; events cost host time)")
@@ -67,11 +72,29 @@ def algorithmic_bytes(stats: dict, frames: int, W: int, H: int, voxel_bytes: int
     return {"integrate": a_int, "alloc_scan": a_alloc, "raycast": a_ray}
 
 
+def make_stream(args, n_frames: int = 0):
+    """Frame source of the run: SLAMBench .raw + ground truth (configs 1, 3) or the analytic stream."""
+    if args.raw:
+        from supereight_amd.rawio import RawStream
+        from supereight_amd.synthetic import intrinsics
+        if not args.traj:
+            raise SystemExit("--raw needs --traj (ground-truth poses are injected, as the reference's apps do with -g)")
+        ip = [float(v) * args.dim for v in args.init_pose.split(",")]
+        st = RawStream(args.raw, args.traj, intrinsics(args.width, negative_fy=True), ip, max_frames=n_frames)
+        if (st.width, st.height) != (args.width, args.height):
+            raise SystemExit(f"{args.raw}: frames are {st.width}x{st.height}, --width/--height say {args.width}x{args.height}")
+        if n_frames and len(st) < n_frames:
+            raise SystemExit(f"{args.raw}: {len(st)} frames, {n_frames} needed (--steps / --warmup)")
+        return st, f"SLAMBench .raw stream {os.path.basename(args.raw)} (ICL-NUIM camera, negative fy)"
+    from supereight_amd.synthetic import SyntheticStream
+    name = "synthetic room+sphere depth stream" + (" through the ICL-NUIM camera (negative fy)" if args.icl_like else "")
+    return SyntheticStream(args.width, args.height, args.dim, negative_fy=args.icl_like), name
+
+
 def cpu_baseline(args, n_timed: int):
     """Times the CPU oracle on frames 0..3 (warm-up, executed but excluded as in SURVEY 8(d)) plus
     n_timed frames of the same stream; fps = n / sum(t_integration + t_raycasting)."""
     from oracle import binding
-    from supereight_amd.synthetic import SyntheticStream
     try:
         binding.load(native=True)
         native = True
@@ -82,7 +105,7 @@ def cpu_baseline(args, n_timed: int):
     for _ in range(max(1, args.cpu_reps)):
         o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
         threads = o.lib.so_num_threads()
-        s = SyntheticStream(args.width, args.height, args.dim)
+        s, _ = make_stream(args, 4 + n_timed)
         t_int_sum, t_ray_sum = 0.0, 0.0
         for f in range(4 + n_timed):
             d, pose = s.depth(f), s.pose(f)
@@ -99,7 +122,7 @@ def cpu_baseline(args, n_timed: int):
     reps.sort()
     fps, t_int_sum, t_ray_sum = reps[len(reps) // 2]          # median repetition
     return {"value": fps, "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"frames 4..{3 + n_timed} of the same synthetic stream after 4 executed warm-up frames "
+            "sample": f"frames 4..{3 + n_timed} of the same stream after 4 executed warm-up frames "
                       f"({n_timed} timed frames, median of {len(reps)} repetitions, OpenMP {threads} threads, "
                       f"{'-march=native' if native else '-march=x86-64-v3'} build)",
             "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed,
@@ -159,7 +182,7 @@ def main():
     F = warm + K
 
     # ---- inputs: the whole stream resident in HBM before anything is timed
-    stream = SyntheticStream(W, H, dim)
+    stream, stream_name = make_stream(args, F)
     host_depth = np.stack([stream.depth(f) for f in range(F)])
     poses = [stream.pose(f) for f in range(F)]
     k = stream.k
@@ -206,8 +229,8 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": warm,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic room+sphere depth stream {W}x{H} -> {N}^3 / {dim} m "
+            "dtype": "f32", "data": "real (.raw)" if args.raw else "synthetic",
+            "config": {"workload": f"{stream_name} {W}x{H} -> {N}^3 / {dim} m "
                                    f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
                                    f"GT poses, frames {warm}..{F - 1} timed",
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists",

@@ -39,3 +39,77 @@ def read_raw(path: str, with_rgb: bool = False):
 
 def frame_stride(w: int, h: int) -> int:
     return 16 + 2 * w * h + 3 * w * h
+
+
+def quaternion_to_rotation(w, x, y, z) -> np.ndarray:
+    """Eigen::Quaternionf(w, x, y, z).toRotationMatrix() in float32 (no normalisation, as Eigen)."""
+    f = np.float32
+    w, x, y, z = f(w), f(x), f(y), f(z)
+    tx, ty, tz = f(2) * x, f(2) * y, f(2) * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[f(1) - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, f(1) - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, f(1) - (txx + tyy)]], np.float32)
+
+
+def read_groundtruth(path: str, init_pose=(0.0, 0.0, 0.0)):
+    """Ground-truth trajectory as the reference consumes it: every non-comment line ends in
+    ``tx ty tz qx qy qz qw`` (se_apps/include/interface.h:118-151, identity gt transform); the pose handed
+    to the pipeline is ``setPose(gt)``: translation += init_pose (DenseSLAMSystem.h:353-356).
+    Returns a list of camera->world 4x4 float32 matrices."""
+    poses = []
+    ip = np.asarray(init_pose, np.float32)
+    with open(path) as fh:
+        for line in fh:
+            if not line.strip() or line[0] == "#":
+                continue
+            c = line.split()
+            if len(c) < 7:
+                raise ValueError("Invalid ground truth file format. Expected line format: ... tx ty tz qx qy qz qw")
+            tx, ty, tz, qx, qy, qz, qw = (np.float32(v) for v in c[-7:])
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :3] = quaternion_to_rotation(qw, qx, qy, qz)
+            T[:3, 3] = np.array([tx, ty, tz], np.float32) + ip
+            poses.append(T)
+    return poses
+
+
+def write_groundtruth(path: str, poses) -> None:
+    """TUM-style ``timestamp tx ty tz qx qy qz qw`` lines from camera->world matrices (for tests)."""
+    from scipy.spatial.transform import Rotation
+    with open(path, "w") as fh:
+        fh.write("# timestamp tx ty tz qx qy qz qw\n")
+        for i, T in enumerate(poses):
+            q = Rotation.from_matrix(np.asarray(T, np.float64)[:3, :3]).as_quat()   # x, y, z, w
+            t = np.asarray(T, np.float64)[:3, 3]
+            fh.write(f"{i} {t[0]:.9g} {t[1]:.9g} {t[2]:.9g} {q[0]:.9g} {q[1]:.9g} {q[2]:.9g} {q[3]:.9g}\n")
+
+
+class RawStream:
+    """Frame source over a SLAMBench .raw file + ground-truth trajectory with the interface of
+    SyntheticStream (``depth(f)`` in metres, ``pose(f)``, ``k``): BASELINE.json configs 1 and 3."""
+
+    def __init__(self, raw_path: str, traj_path: str, k, init_pose=(0.0, 0.0, 0.0), max_frames: int = 0):
+        self.frames = []
+        for d in read_raw(raw_path):
+            self.frames.append(d)
+            if max_frames and len(self.frames) >= max_frames:
+                break
+        if not self.frames:
+            raise ValueError(f"{raw_path}: no frames")
+        self.poses = read_groundtruth(traj_path, init_pose)
+        if len(self.poses) < len(self.frames):
+            raise ValueError(f"{traj_path}: {len(self.poses)} poses for {len(self.frames)} frames")
+        self.height, self.width = self.frames[0].shape
+        self.k = np.asarray(k, np.float32)
+
+    def __len__(self):
+        return len(self.frames)
+
+    def depth(self, frame: int) -> np.ndarray:
+        return self.frames[frame].astype(np.float32) / np.float32(1000.0)   # mm2metersKernel: depth / 1000.0f
+
+    def pose(self, frame: int) -> np.ndarray:
+        return self.poses[frame]

@@ -27,9 +27,12 @@ HOLE_SEED = 54321
 HOLE_FRACTION = np.float32(0.02)
 
 
-def intrinsics(width: int) -> np.ndarray:
-    """(fx, fy, cx, cy) scaled from the 640-wide ICL-NUIM camera."""
-    return (np.array([481.2, 480.0, 320.0, 240.0], dtype=np.float64) * (width / 640.0)).astype(np.float32)
+def intrinsics(width: int, negative_fy: bool = False) -> np.ndarray:
+    """(fx, fy, cx, cy) scaled from the 640-wide ICL-NUIM camera.  ``negative_fy``: the ICL-NUIM
+    convention proper (``-k 481.2,-480,320,240``, README.md:80 of the reference): image rows run
+    against the camera's +y, which is what BASELINE.json configs 1 and 3 use."""
+    fy = -480.0 if negative_fy else 480.0
+    return (np.array([481.2, fy, 320.0, 240.0], dtype=np.float64) * (width / 640.0)).astype(np.float32)
 
 
 def pose(frame: int, dim: float) -> np.ndarray:
@@ -60,9 +63,9 @@ class HoleStream:
         return np.where(v >= 1, np.nextafter(np.float32(1), np.float32(0)), v).astype(np.float32)
 
 
-def render_depth_mm(frame: int, width: int, height: int, dim: float) -> np.ndarray:
+def render_depth_mm(frame: int, width: int, height: int, dim: float, negative_fy: bool = False) -> np.ndarray:
     """uint16 millimetre depth image of the analytic scene (no holes)."""
-    k = intrinsics(width).astype(np.float64)
+    k = intrinsics(width, negative_fy).astype(np.float64)
     T = pose(frame, dim).astype(np.float64)
     xs = (np.arange(width) + 0.5 - k[2]) / k[0]
     ys = (np.arange(height) + 0.5 - k[3]) / k[1]
@@ -93,9 +96,10 @@ class SyntheticStream:
     """Iterator-free frame source: ``depth(f)`` must be called for f = 0, 1, 2, ... in order
     (the hole stream is one RNG for the whole run, as in the survey's probe)."""
 
-    def __init__(self, width: int, height: int, dim: float, holes: bool = True):
+    def __init__(self, width: int, height: int, dim: float, holes: bool = True, negative_fy: bool = False):
         self.width, self.height, self.dim = width, height, float(dim)
-        self.k = intrinsics(width)
+        self.negative_fy = negative_fy
+        self.k = intrinsics(width, negative_fy)
         self._holes = HoleStream() if holes else None
         self._next = 0
 
@@ -103,7 +107,7 @@ class SyntheticStream:
         if frame != self._next:
             raise ValueError("SyntheticStream frames must be requested in order")
         self._next += 1
-        mm = render_depth_mm(frame, self.width, self.height, self.dim)
+        mm = render_depth_mm(frame, self.width, self.height, self.dim, self.negative_fy)
         d = mm.astype(np.float32) / np.float32(1000.0)   # mm2metersKernel: depth / 1000.0f
         if self._holes is not None:
             u = self._holes.uniform(self.width * self.height).reshape(self.height, self.width)

@@ -9,8 +9,8 @@ from supereight_amd.pipeline import DenseSLAMPipeline
 from supereight_amd.synthetic import SyntheticStream
 
 
-def run_both(field, W, H, N, dim, mu, frames, holes=True, max_blocks=0, on_frame=None):
-    stream = SyntheticStream(W, H, dim, holes=holes)
+def run_both(field, W, H, N, dim, mu, frames, holes=True, max_blocks=0, on_frame=None, negative_fy=False):
+    stream = SyntheticStream(W, H, dim, holes=holes, negative_fy=negative_fy)
     cpu = OraclePipeline(field, N, dim, W, H)
     gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field, max_blocks=max_blocks)
     cpu.count_stats(True)

@@ -97,3 +97,32 @@ def test_synthetic_stream_properties():
     assert np.allclose(u, [0.911640763, 0.509720981, 0.623824835, 0.183354408, 0.791803837], atol=1e-8)
     pts = np.array([[0.05 * 4.8, 1.0, 1.0], [2.4, 2.4, 0.62 * 4.8 - 0.08 * 4.8]])
     assert np.allclose(surface_distance(pts, 4.8), 0, atol=1e-6)
+
+
+def test_raw_stream_with_groundtruth_roundtrip(tmp_path):
+    """BASELINE.json configs 1 / 3 harness: a SLAMBench .raw file + TUM-style ground truth read back as
+    the frame source of bench.py (RawStream) reproduces the frames exactly and the poses to float accuracy;
+    readNextPose's quaternion -> matrix and setPose's init-pose offset are the reference's
+    (se_apps/include/interface.h:118-151, DenseSLAMSystem.h:353-356)."""
+    from supereight_amd import rawio
+    from supereight_amd.synthetic import SyntheticStream, render_depth_mm, intrinsics
+    W, H, dim, F = 64, 48, 4.8, 5
+    s = SyntheticStream(W, H, dim, holes=False, negative_fy=True)
+    mm = [render_depth_mm(f, W, H, dim, negative_fy=True) for f in range(F)]
+    init = np.array([0.34, 0.5, 0.24], np.float32) * np.float32(dim)
+    rel = []
+    for f in range(F):
+        T = s.pose(f).copy(); T[:3, 3] -= init; rel.append(T)          # what a gt file holds: poses relative to the start
+    rawio.write_raw(str(tmp_path / "s.raw"), mm)
+    rawio.write_groundtruth(str(tmp_path / "s.gt"), rel)
+    rs = rawio.RawStream(str(tmp_path / "s.raw"), str(tmp_path / "s.gt"), intrinsics(W, True), init)
+    assert len(rs) == F and (rs.width, rs.height) == (W, H) and rs.k[1] < 0
+    for f in range(F):
+        assert (rs.depth(f) == s.depth(f)).all()
+        assert np.abs(rs.pose(f) - s.pose(f)).max() < 2e-6
+    # Eigen's toRotationMatrix for a known quaternion: 90 degrees about +z
+    R = rawio.quaternion_to_rotation(np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5))
+    assert np.abs(R - np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32)).max() < 1e-6
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.gt").write_text("0 1 2 3\n")
+        rawio.read_groundtruth(str(tmp_path / "bad.gt"))

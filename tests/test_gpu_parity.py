@@ -21,12 +21,15 @@ CASES = [
     ("sdf_320x240_1024", SDF, 320, 240, 1024, 4.8, 0.1, 5),     # configs[2] geometry, smaller image
     ("ofusion_160x120_256", OFUSION, 160, 120, 256, 2.4, 0.02, 6),
     ("ofusion_640x480_512", OFUSION, 640, 480, 512, 4.8, 0.008, 5),   # configs[4], the reference's own ofusion mu (Makefile:39)
+    # ICL-NUIM camera convention of configs[0] / configs[2] (-k 481.2,-480,320,240: negative fy)
+    ("icl_like_sdf_320x240_512", SDF, 320, 240, 512, 4.8, 0.1, 5),
+    ("icl_like_ofusion_160x120_256", OFUSION, 160, 120, 256, 2.4, 0.02, 5),
 ]
 
 
 @pytest.mark.parametrize("name,field,W,H,N,dim,mu,frames", CASES, ids=[c[0] for c in CASES])
 def test_stream_parity(name, field, W, H, N, dim, mu, frames):
-    cpu, gpu, recs = run_both(field, W, H, N, dim, mu, frames)
+    cpu, gpu, recs = run_both(field, W, H, N, dim, mu, frames, negative_fy=name.startswith("icl_like"))
     m = compare_maps(cpu, gpu)
     print(name, "map:", json.dumps(m))
     assert cpu.stats()["oob"] == 0          # no sample left the volume -> reference behaviour is defined

@@ -13,9 +13,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("field,W,H,N,dim,mu,frames", [(SDF, 320, 240, 256, 4.8, 0.1, 9), (SDF, 640, 480, 512, 4.8, 0.1, 7),
-                                                         (OFUSION, 320, 240, 256, 4.8, 0.02, 7)], ids=["sdf-320", "sdf-640", "ofusion-320"])
+                                                         (OFUSION, 320, 240, 256, 4.8, 0.02, 7), (SDF, 320, 240, 256, 4.8, 0.1, -7)],
+                         ids=["sdf-320", "sdf-640", "ofusion-320", "sdf-320-icl-negative-fy"])
 def test_slam_loop_with_tracking(field, W, H, N, dim, mu, frames):
-    s = SyntheticStream(W, H, dim)
+    negative_fy, frames = frames < 0, abs(frames)       # ICL-NUIM convention: vertex2normalKernel<true> (DenseSLAMSystem.cpp:160-163)
+    s = SyntheticStream(W, H, dim, negative_fy=negative_fy)
     cpu = OraclePipeline(field, N, dim, W, H)
     gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field)
     pose_c = s.pose(0).copy()
