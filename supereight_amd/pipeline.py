@@ -77,6 +77,9 @@ def load_library(rebuild: bool = True):
     global _LIB
     if _LIB is None:
         path = _build.LIB
+        alt = os.environ.get("SE_HIP_LIB")   # A/B of kernel variants built to another path (tools/)
+        if alt:
+            path, rebuild = alt, False
         if rebuild:
             try:
                 path = _build.build()

@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from supereight_amd.pipeline import DenseSLAMPipeline, SDF, OFUSION
 from supereight_amd.synthetic import SyntheticStream
-W, H, N, dim, mu = 640, 480, int(os.environ.get("RES", 512)), 4.8, 0.1
+W, H, N, dim, mu = 640, 480, int(os.environ.get("RES", 512)), 4.8, float(os.environ.get("MU", 0.1))
+FIELD = OFUSION if os.environ.get("FIELD", "sdf") == "ofusion" else SDF
 s = SyntheticStream(W, H, dim)
-p = DenseSLAMPipeline((W, H), N, dim)
+p = DenseSLAMPipeline((W, H), N, dim, field_type=FIELD)
 for f in range(14):
     p.set_depth(s.depth(f)); p.setPose(s.pose(f))
     p.integration(s.k, 1, mu, f)
