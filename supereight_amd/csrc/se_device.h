@@ -37,8 +37,7 @@ enum { S_PROBES = 0, S_NEWKEYS = 1, S_SWEPT = 2, S_NODES = 3, S_GETS = 4, S_INTE
 struct DevMap {
   uint32_t* tab;
   uint32_t off[SE_MAX_LEVELS];
-  uint32_t* occ;                  // occupancy bit pyramid: level l has 8^l bits in Morton order at word woff[l]
-  uint32_t woff[SE_MAX_LEVELS + 1];
+  uint32_t* occ;                  // occupancy bits in heap order: octant (level l, Morton index c) is bit (1 << 3l) | c
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
@@ -133,15 +132,17 @@ __device__ __forceinline__ uint32_t tab_index_packed(const DevMap& m, int l, uin
 __device__ __forceinline__ uint32_t morton30(int x, int y, int z) {
   return (uint32_t)(se_expand21_d((unsigned long long)x) | (se_expand21_d((unsigned long long)y) << 1) | (se_expand21_d((unsigned long long)z) << 2));
 }
-// word offset of level l in occ[]: levels hold max(1, 8^l / 32) words; level l starts at word
-// (8^l >> 7) + l (a quarter of its own size plus a few words: all lower levels fit below it).  A
-// branch-free closed form because l is a per-lane value in the ray traversal (indexing the by-value
-// DevMap arrays with a vector index would spill them to scratch).
-__host__ __device__ __forceinline__ uint32_t occ_woff(int l) { return ((1u << (3 * l)) >> 7) + (uint32_t)l; }
+// Occupancy bit of an octant = its heap code (1 << 3l) | morton(x, y, z): the root is code 1 and the
+// children of code n are 8n .. 8n+7, so the eight sibling bits of a parent are byte n of the array and
+// a ray traversal carries one integer per node with no per-level offsets (l is a per-lane value there;
+// indexing by-value DevMap arrays with it would spill them to scratch).  Levels <= L occupy the first
+// 2 * 8^L bits.
+__host__ __device__ __forceinline__ size_t occ_words_upto(int l) { return l < 2 ? 1 : ((size_t)2 << (3 * l)) / 32; }
+__device__ __forceinline__ uint32_t occ_code(int l, int x, int y, int z) { return (1u << (3 * l)) | morton30(x, y, z); }
 __device__ __forceinline__ void occ_set(const DevMap& m, int l, int x, int y, int z) {
   if (m.defer_occ) return;
-  const uint32_t code = morton30(x, y, z);
-  atomicOr(&m.occ[m.woff[l] + (code >> 5)], 1u << (code & 31u));
+  const uint32_t code = occ_code(l, x, y, z);
+  atomicOr(&m.occ[code >> 5], 1u << (code & 31u));
 }
 __device__ __forceinline__ bool in_volume(const DevMap& m, int x, int y, int z) {
   return (unsigned)x < (unsigned)m.size && (unsigned)y < (unsigned)m.size && (unsigned)z < (unsigned)m.size;

@@ -285,7 +285,9 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   cl = std::min(cl, p->leaf_level);
   a.cache_levels = cl;
   // staged region = words [0, end of level cl)
-  a.cache_words = cl > 0 ? (int)(occ_woff(cl) + std::max<size_t>(1, ((size_t)1 << (3 * cl)) / 32)) : 1;
+  a.cache_words = (int)occ_words_upto(cl);
+  a.cache_codes = 2u << (3 * cl);
+  a.has_deep = cl < p->leaf_level - 1 ? 1 : 0;
   a.stack_depth = p->leaf_level;
   if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
   // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
@@ -380,9 +382,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   for (int l = 1; l <= p->leaf_level; ++l) { m.off[l] = (uint32_t)off; off += (size_t)1 << (3 * l); }
   p->tab_entries = off;
   m.leaf_off = m.off[p->leaf_level];
-  for (int l = 0; l <= SE_MAX_LEVELS; ++l) m.woff[l] = 0;
-  for (int l = 1; l <= p->leaf_level + 1; ++l) m.woff[l] = occ_woff(l);
-  p->occ_words = (size_t)occ_woff(p->leaf_level) + std::max<size_t>(1, ((size_t)1 << (3 * p->leaf_level)) / 32);
+  p->occ_words = occ_words_upto(p->leaf_level);
   const size_t cells = (size_t)1 << (3 * p->leaf_level);
   // Dense mode (default): one 4 KB brick slot per cell of the block grid, addressed by position --
   // 1 GiB at 512^3, 8 GiB at 1024^3, 64 GiB at 2048^3 of the 288 GB; bricks are pre-set to

@@ -238,8 +238,8 @@ __device__ __forceinline__ void se_occ_commit(const DevMap& m) {
     const int sh = m.max_level - level;
     int x = (int)(se_compact21(code) >> sh), y = (int)(se_compact21(code >> 1) >> sh), z = (int)(se_compact21(code >> 2) >> sh);
     for (int l = level; l >= 1; --l) {
-      const uint32_t c = morton30(x, y, z);
-      atomicOr(&m.occ[occ_woff(l) + (c >> 5)], 1u << (c & 31u));
+      const uint32_t c = occ_code(l, x, y, z);
+      atomicOr(&m.occ[c >> 5], 1u << (c & 31u));
       x >>= 1; y >>= 1; z >>= 1;
     }
   }
@@ -557,10 +557,12 @@ struct RayArgs {
   int min_scale;     // CAST_STACK_DEPTH - log2(size / 8)
   int W, H, row_begin, row_end;
   int cache_levels;  // occupancy levels 1..cache_levels are staged in LDS
-  int cache_words;   // = woff[cache_levels + 1] - woff[1]
+  int cache_words;   // = occ_words_upto(cache_levels)
+  uint32_t cache_codes;  // heap codes below this value are staged (= 2 * 8^cache_levels)
+  int has_deep;          // there are non-leaf levels beyond the staged ones (volumes > 512^3)
   int stack_depth;   // ray stack slots (= leaf level)
   int xcd_swizzle;
-  int debug_phases;  // diagnostic: bit0 = skip march + gradient, bit1 = skip gradient (results are then wrong)
+  int debug_phases;  // diagnostic: bit0 = skip march + gradient, bit1 = skip gradient, bit2 = skip the traversal (results are then wrong)
 };
 
 struct BlkCache { int bx, by, bz; uint32_t e; };
@@ -700,12 +702,19 @@ __device__ __forceinline__ f3 se_grad(const DevMap& m, const FieldConst fc, f3 p
 }
 
 struct RaySpan { float tcmin, tmax; };
+// se::ray_iterator (se_core/include/se/ray_iterator.hpp:53-250) up to the first leaf, on the occupancy
+// bits.  Same float arithmetic on t and pos as the reference; what is restated is the integer side:
+//  * a node is its heap code (occ_code), the child test is one bit of one word;
+//  * `idx` is not carried: pos is the node's corner in [1, 2)^3, an exact multiple of the node size, so
+//    idx bit a is bit `scale` of the mantissa of pos.a (which is how the reference's pop recomputes it);
+//  * advance: subtracting scale_exp2 flips exactly bit `scale` unless it borrows, so old ^ new of the
+//    three coordinates is the reference's differing_bits, and "leaves the parent" (idx & step_mask) is
+//    "some bit above `scale` changed".
 __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs& a, f3 origin, f3 direction,
                                                  const uint32_t* s_occ, uint32_t* s_par, float* s_tmax) {
   const int tid = threadIdx.x;
   f3 pos = {1.0f, 1.0f, 1.0f};
-  int idx = 0;
-  uint32_t parent = 0u;  // root
+  uint32_t parent = 1u;  // root
   float scale_exp2 = 0.5f;
   int scale = 22;
   const float eps = a.epsilon;
@@ -716,89 +725,85 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   const f3 scaled_origin = f3_add(f3_div(origin, m.dim), {1.f, 1.f, 1.f});
   const f3 t_coef = f3_scale(-1.f, {1.f / fabsf(d.x), 1.f / fabsf(d.y), 1.f / fabsf(d.z)});
   f3 t_bias = f3_mul(t_coef, scaled_origin);
-  int octant_mask = 7;
-  if (d.x > 0.0f) { octant_mask ^= 1; t_bias.x = 3.0f * t_coef.x - t_bias.x; }
-  if (d.y > 0.0f) { octant_mask ^= 2; t_bias.y = 3.0f * t_coef.y - t_bias.y; }
-  if (d.z > 0.0f) { octant_mask ^= 4; t_bias.z = 3.0f * t_coef.z - t_bias.z; }
+  uint32_t om = 0u;     // octant_mask ^ 7
+  if (d.x > 0.0f) { om ^= 1u; t_bias.x = 3.0f * t_coef.x - t_bias.x; }
+  if (d.y > 0.0f) { om ^= 2u; t_bias.y = 3.0f * t_coef.y - t_bias.y; }
+  if (d.z > 0.0f) { om ^= 4u; t_bias.z = 3.0f * t_coef.z - t_bias.z; }
   float t_min = fmaxf(fmaxf(2.0f * t_coef.x - t_bias.x, 2.0f * t_coef.y - t_bias.y), 2.0f * t_coef.z - t_bias.z);
   float t_max = fminf(fminf(t_coef.x - t_bias.x, t_coef.y - t_bias.y), t_coef.z - t_bias.z);
   float h = t_max;
   t_min = fmaxf(t_min, a.nearp / m.dim);
   t_max = fminf(t_max, a.farp / m.dim);
   const float tmax_m = t_max * m.dim;
-  if (1.5f * t_coef.x - t_bias.x > t_min) { idx ^= 1; pos.x = 1.5f; }
-  if (1.5f * t_coef.y - t_bias.y > t_min) { idx ^= 2; pos.y = 1.5f; }
-  if (1.5f * t_coef.z - t_bias.z > t_min) { idx ^= 4; pos.z = 1.5f; }
-  for (int i = 0; i < a.stack_depth; ++i) { s_par[i * SE_WG + tid] = 0u; s_tmax[i * SE_WG + tid] = 0.f; }
+  if (1.5f * t_coef.x - t_bias.x > t_min) pos.x = 1.5f;
+  if (1.5f * t_coef.y - t_bias.y > t_min) pos.y = 1.5f;
+  if (1.5f * t_coef.z - t_bias.z > t_min) pos.z = 1.5f;
+  // a stack slot that was never pushed reads as the first node of its level (code 1 << 3i), t_max 0
+  for (int i = 0; i < a.stack_depth; ++i) { s_par[i * SE_WG + tid] = 1u << (3 * i); s_tmax[i * SE_WG + tid] = 0.f; }
 
-  f3 t_corner = {0.f, 0.f, 0.f};
-  float tc_max = 0.f;
-  const int om = octant_mask ^ 7;
   uint32_t gw_index = 0xFFFFFFFFu, gw_word = 0u;  // last occupancy word fetched from global memory (levels between cache and leaf)
   uint32_t leaf_byte = 0u;                        // the 8 leaf-level sibling bits of the current parent
-  const uint8_t* occ_leaf_bytes = (const uint8_t*)(m.occ + occ_woff(m.leaf_level));
-  for (int guard = 0; guard < 4096 && scale < 23; ++guard) {
-    t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
-    tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
-    const int cidx = idx ^ om;
-    const int clevel = 23 - scale;  // level of the child
-    const uint32_t child = (parent << 3) | (uint32_t)cidx;
+  const uint8_t* occ_bytes = (const uint8_t*)m.occ;
+  // One trip = one node.  Some lanes of a wave descend while others advance on nearly every trip, so
+  // both updates are computed for every lane and selected (straight-line code, no exec-mask juggling);
+  // only the rare events are branches: leaving a parent (stack read), entering a leaf parent (sibling
+  // byte load) and the global occupancy word of volumes > 512^3.
+  const int max_trips = (a.debug_phases & 4) ? 0 : 4096;   // diagnostic: no traversal at all
+  for (int guard = 0; guard < max_trips && scale < 23; ++guard) {
+    const f3 t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
+    const float tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
+    const uint32_t us = (uint32_t)scale;
+    const uint32_t ox = __float_as_uint(pos.x), oy = __float_as_uint(pos.y), oz = __float_as_uint(pos.z);
+    const uint32_t cidx = (__builtin_amdgcn_ubfe(ox, us, 1u) | (__builtin_amdgcn_ubfe(oy, us, 1u) << 1) | (__builtin_amdgcn_ubfe(oz, us, 1u) << 2)) ^ om;
+    const uint32_t child = (parent << 3) | cidx;
     const bool at_leaves = scale == a.min_scale;
     // occupancy test: leaf level -> the sibling byte fetched when this parent was entered;
     // staged levels -> LDS; levels in between (volumes > 512^3) -> global word, cached per word
-    const uint32_t w = occ_woff(clevel) + (child >> 5);
-    uint32_t word = s_occ[at_leaves || clevel > a.cache_levels ? 0u : w];
+    const bool deep = a.has_deep && child >= a.cache_codes;
+    uint32_t word = s_occ[(at_leaves || deep) ? 0u : (child >> 5)];
     asm volatile("" : "+v"(word));  // keep the LDS load an LDS load
-    uint32_t shift = child & 31u;
-    if (at_leaves) { word = leaf_byte; shift = (uint32_t)cidx; }
-    else if (clevel > a.cache_levels) {
-      if (w != gw_index) { gw_index = w; gw_word = m.occ[w]; }
-      word = gw_word;
+    if (a.has_deep) {
+      if (deep && !at_leaves) {
+        const uint32_t w = child >> 5;
+        if (w != gw_index) { gw_index = w; gw_word = m.occ[w]; }
+        word = gw_word;
+      }
     }
+    word = at_leaves ? leaf_byte : word;
+    const uint32_t shift = at_leaves ? cidx : (child & 31u);
     const bool exists = (word >> shift) & 1u;
     if (at_leaves && exists) break;  // leaf found: t_min is its entry distance
-    if (exists && t_min <= t_max) {
-      // descend (ray_iterator.hpp:172-199)
-      const float tv_max = fminf(t_max, tc_max);
-      const float half = scale_exp2 * 0.5f;
-      const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
-      if (tc_max < h) { s_par[(22 - scale) * SE_WG + tid] = parent; s_tmax[(22 - scale) * SE_WG + tid] = t_max; }
-      h = tc_max;
-      parent = child;
-      scale--;
-      if (scale == a.min_scale) leaf_byte = occ_leaf_bytes[child];  // issued now, first used next trip
-      scale_exp2 = half;
-      idx = ((t_center.x > t_min) ? 1 : 0) | ((t_center.y > t_min) ? 2 : 0) | ((t_center.z > t_min) ? 4 : 0);
-      pos.x += (idx & 1) ? scale_exp2 : 0.f;
-      pos.y += (idx & 2) ? scale_exp2 : 0.f;
-      pos.z += (idx & 4) ? scale_exp2 : 0.f;
-      t_max = tv_max;
-      continue;
-    }
+    const bool desc = exists && t_min <= t_max;
+    // descend (ray_iterator.hpp:172-199)
+    const float half = scale_exp2 * 0.5f;
+    const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
+    if (desc && tc_max < h) { s_par[(22 - scale) * SE_WG + tid] = parent; s_tmax[(22 - scale) * SE_WG + tid] = t_max; }
+    const f3 dpos = {pos.x + ((t_center.x > t_min) ? half : 0.f), pos.y + ((t_center.y > t_min) ? half : 0.f), pos.z + ((t_center.z > t_min) ? half : 0.f)};
     // advance_ray (ray_iterator.hpp:116-167)
-    const int step_mask = (t_corner.x <= tc_max ? 1 : 0) | (t_corner.y <= tc_max ? 2 : 0) | (t_corner.z <= tc_max ? 4 : 0);
-    pos.x -= (step_mask & 1) ? scale_exp2 : 0.f;
-    pos.y -= (step_mask & 2) ? scale_exp2 : 0.f;
-    pos.z -= (step_mask & 4) ? scale_exp2 : 0.f;
-    t_min = tc_max;
-    idx ^= step_mask;
-    if ((idx & step_mask) != 0) {
-      unsigned differing_bits = 0;
-      if ((step_mask & 1) != 0) differing_bits |= __float_as_int(pos.x) ^ __float_as_int(pos.x + scale_exp2);
-      if ((step_mask & 2) != 0) differing_bits |= __float_as_int(pos.y) ^ __float_as_int(pos.y + scale_exp2);
-      if ((step_mask & 4) != 0) differing_bits |= __float_as_int(pos.z) ^ __float_as_int(pos.z + scale_exp2);
-      scale = (__float_as_int((float)differing_bits) >> 23) - 127;
+    const f3 apos = {pos.x - ((t_corner.x <= tc_max) ? scale_exp2 : 0.f), pos.y - ((t_corner.y <= tc_max) ? scale_exp2 : 0.f),
+                     pos.z - ((t_corner.z <= tc_max) ? scale_exp2 : 0.f)};
+    const uint32_t differing_bits = (ox ^ __float_as_uint(apos.x)) | (oy ^ __float_as_uint(apos.y)) | (oz ^ __float_as_uint(apos.z));
+    const bool pop = !desc && differing_bits > (1u << us);
+    // select
+    t_max = desc ? fminf(t_max, tc_max) : t_max;
+    t_min = desc ? t_min : tc_max;
+    h = desc ? tc_max : h;
+    parent = desc ? child : parent;
+    scale = desc ? scale - 1 : scale;
+    scale_exp2 = desc ? half : scale_exp2;
+    pos.x = desc ? dpos.x : apos.x; pos.y = desc ? dpos.y : apos.y; pos.z = desc ? dpos.z : apos.z;
+    if (desc && scale == a.min_scale) leaf_byte = occ_bytes[child];  // issued now, first used next trip
+    if (pop) {
+      // the highest differing bit is the scale of the first ancestor the ray is still inside
+      scale = 31 - __clz(differing_bits);            // == (float_as_int((float)differing_bits) >> 23) - 127, differing_bits < 2^24
       scale_exp2 = __int_as_float((scale - 23 + 127) << 23);
       const int slot = 22 - scale;
       if (slot >= 0 && slot < a.stack_depth) { parent = s_par[slot * SE_WG + tid]; t_max = s_tmax[slot * SE_WG + tid]; }
-      if (scale >= 0 && scale < 31) {
-        const int shx = __float_as_int(pos.x) >> scale;
-        const int shy = __float_as_int(pos.y) >> scale;
-        const int shz = __float_as_int(pos.z) >> scale;
-        pos.x = __int_as_float(shx << scale);
-        pos.y = __int_as_float(shy << scale);
-        pos.z = __int_as_float(shz << scale);
-        idx = (shx & 1) | ((shy & 1) << 1) | ((shz & 1) << 2);
+      if (scale < 23) {
+        const uint32_t keep = 0xFFFFFFFFu << scale;
+        pos.x = __uint_as_float(__float_as_uint(pos.x) & keep);
+        pos.y = __uint_as_float(__float_as_uint(pos.y) & keep);
+        pos.z = __uint_as_float(__float_as_uint(pos.z) & keep);
       }
       h = 0.0f;
     }

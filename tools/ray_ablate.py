@@ -10,7 +10,7 @@ for f in range(14):
     p.set_depth(s.depth(f)); p.setPose(s.pose(f))
     p.integration(s.k, 1, mu, f)
 p.sync()
-for ph, name in ((0, "full"), (2, "no gradient"), (1, "first-leaf search only")):
+for ph, name in ((0, "full"), (2, "no gradient"), (1, "first-leaf search only"), (5, "ray set-up + LDS staging + stores only")):
     os.environ["SE_HIP_DEBUG_RAY_PHASES"] = str(ph)
     p.enable_timing(True)
     for _ in range(20):
