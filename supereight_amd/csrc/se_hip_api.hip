@@ -690,6 +690,7 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   a.timestamp = (1.f / 30.f) * frame;                // DenseSLAMSystem.cpp:243
   a.W = p->cfg.width; a.H = p->cfg.height;
   a.bspline = p->bspline; a.logodds = p->logodds;
+  a.ctr_mirror = p->ctr_host;   // the kernel refreshes the host copy of the counters (next frame's launch geometry)
   const dim3 block(SE_WG);
   {
     // one launch: blocks (one wave each) then nodes.  The block count lives on the device; the grid is
@@ -708,8 +709,6 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
     }
   }
   hipEventRecord(p->ev_sweep, p->stream);   // the next frame's scan / depth upload may start behind this point
-  // refresh the host copy of the counters for the next frame's launch geometry (no synchronisation)
-  hipMemcpyAsync(p->ctr_host, m.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream);
   HIP_TRY(hipGetLastError());
   return 1;
 }

@@ -320,6 +320,7 @@ struct IntegArgs {
   const float* logodds;    // OFusion: log2f(s/(1-s)) for every (Q1 index, Q2 index) pair, see se_hip_api.hip
   int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan first
   int debug;               // diagnostic: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
+  uint32_t* ctr_mirror;    // pinned host copy of ctr[] (launch-geometry estimate of the next sweep), may be null
 };
 
 #define SE_LO_DIM 1002  // 0..999 table entries, 1000 = "0" (t < -3), 1001 = "1" (t > 3)
@@ -477,6 +478,9 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   const int lx = lane & 7, ly = lane >> 3;
   const float fx = (float)lx;
   unsigned long long swept = 0;
+  // counters as this sweep sees them -> pinned host memory (posted write; sizes the next sweep's grid
+  // without a device-to-host copy between this kernel and the raycast)
+  if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
   if (a.commit_occ) se_occ_commit(m);   // nothing in this kernel reads occ[]; the raycast that follows does
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
@@ -642,6 +646,39 @@ __device__ __forceinline__ float se_interp(const DevMap& m, const FieldConst fc,
     const float v = m.vx[vi];
     p[k] = ek ? v : missing;
   }
+  return (((p[0] * (1 - fx) + p[1] * fx) * (1 - fy) + (p[2] * (1 - fx) + p[3] * fx) * fy) * (1 - fz) +
+          ((p[4] * (1 - fx) + p[5] * fx) * (1 - fy) + (p[6] * (1 - fx) + p[7] * fx) * fy) * fz);
+}
+
+// Dense grid: the address of every corner of an interpolation cell follows from the position alone, so
+// the SDF march can fetch the corners of a sample together with the sample itself.  Same cell
+// arithmetic as se_interp; the block of corner k is ((lx + (k & 1)) >> 3, ...), the block gather_points
+// picks in every cross case.
+struct InterpCell { float fx, fy, fz, missing; uint32_t ok; };
+__device__ __forceinline__ InterpCell se_interp_cell_dense(const DevMap& m, const FieldConst fc, f3 pos, size_t vi[8]) {
+  const float flx = floorf(pos.x), fly = floorf(pos.y), flz = floorf(pos.z);
+  const int bx = cvt_i32(flx), by = cvt_i32(fly), bz = cvt_i32(flz);
+  InterpCell cell;
+  cell.fx = pos.x - flx; cell.fy = pos.y - fly; cell.fz = pos.z - flz;
+  const int lx = max(bx, 0), ly = max(by, 0), lz = max(bz, 0);
+  const bool cx = (lx & 7) == 7, cy = (ly & 7) == 7, cz = (lz & 7) == 7;
+  cell.missing = (cx && cy && cz) ? fc.init_x : fc.empty_x;
+  cell.ok = 0u;
+  const int nb = m.size >> 3;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int x = lx + (k & 1), y = ly + ((k >> 1) & 1), z = lz + (k >> 2);
+    const bool ok = (unsigned)(x >> 3) < (unsigned)nb && (unsigned)(y >> 3) < (unsigned)nb && (unsigned)(z >> 3) < (unsigned)nb;
+    vi[k] = ok ? se_voxel_index(block_linear(m, x >> 3, y >> 3, z >> 3) + 1u, x, y, z) : 0;
+    cell.ok |= ok ? (1u << k) : 0u;
+  }
+  return cell;
+}
+__device__ __forceinline__ float se_interp_blend(const InterpCell& c, const float v[8]) {
+  float p[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p[k] = ((c.ok >> k) & 1u) ? v[k] : c.missing;
+  const float fx = c.fx, fy = c.fy, fz = c.fz;
   return (((p[0] * (1 - fx) + p[1] * fx) * (1 - fy) + (p[2] * (1 - fx) + p[3] * fx) * fy) * (1 - fz) +
           ((p[4] * (1 - fx) + p[5] * fx) * (1 - fy) + (p[6] * (1 - fx) + p[7] * fx) * fy) * fz);
 }
@@ -859,6 +896,17 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
               const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
               qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
             }
+            // Near the surface every step changes the step size, so a batch ends after its first sample
+            // and that sample usually wants the interpolated value: on the dense grid its 8 corners ride
+            // along with the gets instead of costing a round trip of their own.
+            InterpCell cell0;
+            float cv0[8];
+            if (DENSE) {
+              size_t vi0[8];
+              cell0 = se_interp_cell_dense(m, fc, f3_scale(a.inv_voxel, q[0]), vi0);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) cv0[k] = m.vx[vi0[k]];
+            }
 #pragma unroll
             for (int i = 0; i < SE_SPEC; ++i) {
               if (!(t < tfar)) { done = true; break; }
@@ -870,8 +918,12 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
               } else {
                 f_tt = dx;
                 if ((double)f_tt <= 0.1 && f_tt >= -0.5f) {
-                  c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
-                  f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
+                  if (DENSE && i == 0) {
+                    f_tt = se_interp_blend(cell0, cv0);
+                  } else {
+                    c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
+                    f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
+                  }
                   if (STATS) ++n_interp;
                 }
                 if (f_tt < 0) { done = true; break; }
