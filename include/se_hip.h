@@ -101,6 +101,8 @@ int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* 
 /* Make the scan write its list into caller-owned device memory (e.g. the send buffer of the RCCL
  * allgather); capacity_words includes the count word.  NULL restores the internal buffer. */
 int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_t capacity_words);
+/* The lists must have been produced by work ordered on the scan stream (se_hip_set_scan_stream) or on the
+ * main stream; the call joins the scan stream into the main stream before it reads them. */
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words);
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate,
                            float mu, uint32_t frame);

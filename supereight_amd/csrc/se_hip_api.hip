@@ -644,6 +644,9 @@ int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
+  // The gathered lists were produced on the scan stream (scan kernel, then the caller's all-gather ordered
+  // behind it): fence that stream here so the caller needs no stream join of its own.
+  if (p->overlap && p->side) { HIP_TRY(hipEventRecord(p->ev_scan, p->side)); HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0)); }
   if (int r = join_scan(p, true)) return r;   // the sweep that follows publishes the scan's occupancy bits
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);

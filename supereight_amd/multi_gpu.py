@@ -133,7 +133,7 @@ class ShardedPipeline:
                     else:
                         import torch.distributed as dist
                         dist.all_gather_into_tensor(recv, send, group=self.group)
-                    self.main.wait_stream(self.xs)
+                    # no stream join here: se_hip_alloc_commit fences the scan stream (= xs) itself
                 p.alloc_commit(recv.data_ptr(), self.world, words)
             p.integrate_sweep(k, integration_rate, mu, frame)
         p.raycasting(k, mu, frame)
