@@ -95,6 +95,15 @@ struct se_hip_pipeline {
   const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
   unsigned short* depth_mm = nullptr;
   size_t depth_mm_cap = 0;
+  // host depth images are copied into a ring of pinned buffers and DMA'd from there: the call returns as
+  // soon as the caller's buffer has been read (the reference's preprocessing() is synchronous), the
+  // transfer itself is asynchronous (a pageable hipMemcpyAsync of < 1 MB blocks on the stream instead)
+  static constexpr int kStage = 3;
+  void* stage_host[kStage] = {nullptr, nullptr, nullptr};
+  hipEvent_t stage_done[kStage] = {nullptr, nullptr, nullptr};
+  bool stage_used[kStage] = {false, false, false};
+  size_t stage_cap = 0;
+  int stage_next = 0;
   float* vertex = nullptr;
   float* normal = nullptr;
   float* bspline = nullptr;
@@ -491,6 +500,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   if (p->reduce_out) hipFree(p->reduce_out);
   if (p->reduce_host) hipHostFree(p->reduce_host);
   if (p->ctr_host) hipHostFree(p->ctr_host);
+  for (int i = 0; i < se_hip_pipeline::kStage; ++i) { if (p->stage_host[i]) hipHostFree(p->stage_host[i]); if (p->stage_done[i]) hipEventDestroy(p->stage_done[i]); }
   if (p->own_side && p->side) hipStreamDestroy(p->side);
   if (p->ev_sweep) hipEventDestroy(p->ev_sweep);
   if (p->ev_scan) hipEventDestroy(p->ev_scan);
@@ -529,11 +539,39 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
   return SE_HIP_OK;
 }
 
+// host -> device through the pinned staging ring (see se_hip_pipeline::stage_host)
+int staged_upload(se_hip_pipeline* p, void* dev, const void* host, size_t bytes, hipStream_t s) {
+  // measured on MI355X / ROCm 7.2 (tools/pcie_rate.py): from 1 MB up the runtime's own pageable path (it pins
+  // the pages and DMAs from them) beats a host-side copy into the ring; below that it blocks on the stream
+  if (bytes >= ((size_t)1 << 20)) { HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s)); return SE_HIP_OK; }
+  if (p->stage_cap < bytes) {
+    for (int i = 0; i < se_hip_pipeline::kStage; ++i) {
+      if (p->stage_used[i]) hipEventSynchronize(p->stage_done[i]);
+      if (p->stage_host[i]) hipHostFree(p->stage_host[i]);
+      p->stage_host[i] = nullptr; p->stage_used[i] = false;
+    }
+    p->stage_cap = 0;
+    for (int i = 0; i < se_hip_pipeline::kStage; ++i) {
+      HIP_TRY(hipHostMalloc(&p->stage_host[i], bytes));
+      if (!p->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->stage_done[i], hipEventDisableTiming));
+    }
+    p->stage_cap = bytes;
+  }
+  const int i = p->stage_next;
+  p->stage_next = (i + 1) % se_hip_pipeline::kStage;
+  if (p->stage_used[i]) HIP_TRY(hipEventSynchronize(p->stage_done[i]));   // three uploads ago: long finished
+  std::memcpy(p->stage_host[i], host, bytes);
+  HIP_TRY(hipMemcpyAsync(dev, p->stage_host[i], bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(p->stage_done[i], s));
+  p->stage_used[i] = true;
+  return SE_HIP_OK;
+}
+
 int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m) {
   if (int r = check(p)) return r;
   if (!host_depth_m) return fail(SE_HIP_E_INVALID, "null depth");
   hipStream_t s = upload_stream(p);
-  HIP_TRY(hipMemcpyAsync(p->depth_own, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), hipMemcpyHostToDevice, s));
+  if (int r = staged_upload(p, p->depth_own, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), s)) return r;
   if (!p->overlap) {} else p->upload_on_side = true;
   p->depth = p->depth_own;
   return SE_HIP_OK;
@@ -553,7 +591,7 @@ int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t 
     p->depth_mm_cap = n;
   }
   hipStream_t s = upload_stream(p);
-  HIP_TRY(hipMemcpyAsync(p->depth_mm, host_mm, n * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+  if (int r = staged_upload(p, p->depth_mm, host_mm, n * sizeof(unsigned short), s)) return r;
   hipLaunchKernelGGL(k_mm2meters, dim3((W + 255) / 256, H), dim3(256), 0, s, p->depth_own, W, H, p->depth_mm, in_w, in_w / W);
   if (p->overlap) p->upload_on_side = true;
   HIP_TRY(hipGetLastError());
