@@ -10,7 +10,7 @@
  *   upload; the optional bilateral filter runs on the device in front of tracking()), integration(),
  *   tracking(), raycasting(), setPose()/getPose()/getPosition()/getInitPos(), getIntegrated(), getTracked(),
  *   getModelDimensions()/getModelResolution()/getComputationResolution(), renderVolume()/renderTrack()/
- *   renderDepth(), setViewPose()/getViewPose(), synchroniseDevices().
+ *   renderDepth(), dump_mesh(), setViewPose()/getViewPose(), synchroniseDevices().
  * What differs, because the map lives in HBM:
  *   getMap() returns a host snapshot (MapSnapshot: blocks sorted by Morton key) instead of a
  *   shared_ptr<se::Octree>; getVertex()/getNormal() download vertex_/normal_.
@@ -160,6 +160,9 @@ class DenseSLAMSystem {
   }
   void renderTrack(unsigned char* out, const Eigen::Vector2i& outputSize) { (void)outputSize; ok(se_hip_render_track(h_, out)); }
   void renderDepth(unsigned char* out, const Eigen::Vector2i& outputSize) { (void)outputSize; ok(se_hip_render_depth(h_, out)); }
+
+  /* DenseSLAMSystem.h:224 / DenseSLAMSystem.cpp:302-322: marching cubes of the map into a VTK file */
+  void dump_mesh(const std::string filename) { ok(se_hip_dump_mesh(h_, filename.c_str())); }
   void setViewPose(Eigen::Matrix4f* value = NULL) { viewPose_ = value ? value : &pose_; }   /* DenseSLAMSystem.h:363-372 */
   Eigen::Matrix4f* getViewPose() { return viewPose_; }
 

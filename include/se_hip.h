@@ -161,6 +161,18 @@ int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, fl
  *      nondeterministic under OpenMP). */
 int se_hip_save_map(se_hip_pipeline* p, const char* filename);
 
+/* ---- map export, second half: marching cubes over the allocated blocks
+ * DenseSLAMSystem::dump_mesh (DenseSLAMSystem.cpp:302-322) = se::algorithms::marching_cube
+ * (se_core/include/se/algorithms/meshing.hpp:161-208) with inside(v) = v.x < 0, select(v) = v.x, then writeVtkMesh
+ * (se_denseslam/include/se/commons.h:325-390).  Vertices (which cell edges carry one, and where) are the
+ * reference's; the split of a cell's polygon into triangles follows include/se_mc_table.h, a derived table, not the
+ * reference's edge_tables.h.  A triangle is 9 floats (3 vertices, metres); their order is unspecified, as in the
+ * reference (OpenMP completion order there). */
+int se_hip_mesh_count(se_hip_pipeline* p, int64_t* n_triangles);
+int se_hip_mesh_download(se_hip_pipeline* p, float* host_triangles, int64_t capacity_triangles, int64_t* n_written);
+/* dump_mesh(filename): ASCII VTK polydata in writeVtkMesh's format, triangles sorted for reproducibility */
+int se_hip_dump_mesh(se_hip_pipeline* p, const char* filename);
+
 /* ---- measurement (replaces TICK()/TOCK() + PerfStats, se_shared/timings.h:7-15) */
 #define SE_HIP_K_ALLOC_SCAN 0
 #define SE_HIP_K_ALLOC_COMMIT 1

@@ -105,6 +105,7 @@ def _declare(lib):
         "so_render_track": (None, [c_u8p, C.c_void_p, i32, i32]),
         "so_pipe_render_volume": (None, [vp, c_u8p, c_f32p, c_f32p, c_f32p, f32, f32, c_f32p, c_f32p]),
         "so_pipe_save": (i32, [vp, C.c_char_p]),
+        "so_pipe_mesh": (C.c_longlong, [vp, C.c_void_p, C.c_longlong]),
         "so_num_threads": (i32, []),
         "so_set_num_threads": (None, [i32]),
     }
@@ -200,6 +201,14 @@ class OraclePipeline:
 
     def save(self, filename: str) -> bool:
         return bool(self.lib.so_pipe_save(self.h, filename.encode()))
+
+    def mesh(self) -> np.ndarray:
+        """DenseSLAMSystem::dump_mesh up to the triangle list: (n, 3, 3) float32 vertices, block-pool order."""
+        n = self.lib.so_pipe_mesh(self.h, None, 0)
+        out = np.empty((n, 3, 3), np.float32)
+        if n:
+            self.lib.so_pipe_mesh(self.h, out.ctypes.data, n)
+        return out
 
     def counts(self):
         nb, nn = C.c_int(), C.c_int()

@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libse_hip.so")
 SOURCES = ["se_hip_api.hip"]
-HEADERS = ["se_device.h", "se_kernels.h", os.path.join("..", "..", "include", "se_hip.h")]
+HEADERS = ["se_device.h", "se_kernels.h", "se_track_kernels.h", "se_mesh_kernels.h", os.path.join("..", "..", "include", "se_hip.h"),
+           os.path.join("..", "..", "include", "se_mc_table.h")]
 # -ffp-contract=off is part of the numeric contract (no FMA contraction in device or host code)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
 

@@ -17,6 +17,7 @@
 
 #include "se_kernels.h"
 #include "se_track_kernels.h"
+#include "se_mesh_kernels.h"
 
 namespace {
 
@@ -74,6 +75,8 @@ struct se_hip_pipeline {
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool upload_on_side = false; // the current depth image was uploaded on `side`
   const float* scaled0 = nullptr;   // scaled_depth_[0] of the last se_hip_track
+  bool mc_table_ready = false;   // SE_MC_TRI uploaded to constant memory
+  unsigned long long* mesh_ctr = nullptr;
   bool filter_input = false;   // preprocessing(..., filterInput): tracking sees the bilateral-filtered depth
   bool occ_commit_due = false; // the next sweep kernel must publish the scan's occupancy bits
   // tracking
@@ -500,6 +503,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   if (p->reduce_out) hipFree(p->reduce_out);
   if (p->reduce_host) hipHostFree(p->reduce_host);
   if (p->ctr_host) hipHostFree(p->ctr_host);
+  if (p->mesh_ctr) hipFree(p->mesh_ctr);
   for (int i = 0; i < se_hip_pipeline::kStage; ++i) { if (p->stage_host[i]) hipHostFree(p->stage_host[i]); if (p->stage_done[i]) hipEventDestroy(p->stage_done[i]); }
   if (p->own_side && p->side) hipStreamDestroy(p->side);
   if (p->ev_sweep) hipEventDestroy(p->ev_sweep);
@@ -994,6 +998,81 @@ static int fetch_counters(se_hip_pipeline* p) {
   HIP_TRY(hipMemcpyAsync(p->ctr_host, p->map.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->ctr_host[C_OVERFLOW]) return fail(SE_HIP_E_CAPACITY, p->ctr_host[C_OVERFLOW] == 2 ? "new-key list overflow" : "block / node pool exhausted (raise max_blocks)");
+  return SE_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------- mesh export
+namespace {
+int run_mesh(se_hip_pipeline* p, float* dev_out, unsigned long long capacity, unsigned long long* n) {
+  if (int r = join_scan(p)) return r;
+  if (!p->mc_table_ready) {
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(SE_MC_TRI), SE_MC_TRI_INIT, sizeof(SE_MC_TRI_INIT)));
+    p->mc_table_ready = true;
+  }
+  if (!p->mesh_ctr) HIP_TRY(hipMalloc((void**)&p->mesh_ctr, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(p->mesh_ctr, 0, 2 * sizeof(unsigned long long), p->stream));
+  MeshArgs a{dev_out, p->mesh_ctr, capacity};
+  hipLaunchKernelGGL(k_mesh, dim3(4096), dim3(SE_WG), 0, p->stream, p->map, a);
+  unsigned long long h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, p->mesh_ctr, sizeof h, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *n = dev_out ? h[1] : h[0];
+  return SE_HIP_OK;
+}
+}  // namespace
+
+int se_hip_mesh_count(se_hip_pipeline* p, int64_t* n_triangles) {
+  if (int r = check(p)) return r;
+  if (!n_triangles) return fail(SE_HIP_E_INVALID, "null argument");
+  unsigned long long n = 0;
+  if (int r = run_mesh(p, nullptr, 0, &n)) return r;
+  *n_triangles = (int64_t)n;
+  return SE_HIP_OK;
+}
+
+int se_hip_mesh_download(se_hip_pipeline* p, float* host_triangles, int64_t capacity_triangles, int64_t* n_written) {
+  if (int r = check(p)) return r;
+  if (!host_triangles || capacity_triangles < 0 || !n_written) return fail(SE_HIP_E_INVALID, "bad argument");
+  *n_written = 0;
+  if (capacity_triangles == 0) return SE_HIP_OK;
+  float* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, (size_t)capacity_triangles * 9 * sizeof(float)));
+  unsigned long long n = 0;
+  int r = run_mesh(p, dev, (unsigned long long)capacity_triangles, &n);
+  if (r == SE_HIP_OK) {
+    const size_t w = (size_t)std::min<unsigned long long>(n, (unsigned long long)capacity_triangles);
+    if (hipMemcpy(host_triangles, dev, w * 9 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) r = fail(SE_HIP_E_DEVICE, "hipMemcpy (mesh)");
+    *n_written = (int64_t)w;
+    if (r == SE_HIP_OK && n > (unsigned long long)capacity_triangles) r = fail(SE_HIP_E_CAPACITY, "triangle buffer too small (se_hip_mesh_count gives the size)");
+  }
+  hipFree(dev);
+  return r;
+}
+
+// DenseSLAMSystem::dump_mesh (DenseSLAMSystem.cpp:302-322) + writeVtkMesh (se_denseslam/include/se/commons.h:325-390,
+// no point / cell data).  The reference appends triangles in OpenMP completion order; here they are sorted by
+// their bit patterns so that the file is reproducible.
+int se_hip_dump_mesh(se_hip_pipeline* p, const char* filename) {
+  if (int r = check(p)) return r;
+  if (!filename) return fail(SE_HIP_E_INVALID, "null filename");
+  int64_t n = 0;
+  if (int r = se_hip_mesh_count(p, &n)) return r;
+  std::vector<float> tri((size_t)n * 9);
+  int64_t w = 0;
+  if (n) if (int r = se_hip_mesh_download(p, tri.data(), n, &w)) return r;
+  std::vector<size_t> order((size_t)w);
+  std::iota(order.begin(), order.end(), (size_t)0);
+  std::sort(order.begin(), order.end(), [&](size_t i, size_t j) { return std::memcmp(&tri[9 * i], &tri[9 * j], 36) < 0; });
+  FILE* f = std::fopen(filename, "w");
+  if (!f) return fail(SE_HIP_E_INVALID, std::string("cannot open ") + filename);
+  std::fprintf(f, "# vtk DataFile Version 1.0\nvtk mesh generated from KFusion\nASCII\nDATASET POLYDATA\n");
+  std::fprintf(f, "POINTS %lld FLOAT\n", (long long)(3 * w));
+  for (size_t i : order)
+    for (int v = 0; v < 3; ++v) std::fprintf(f, "%g %g %g\n", tri[9 * i + 3 * v], tri[9 * i + 3 * v + 1], tri[9 * i + 3 * v + 2]);
+  std::fprintf(f, "POLYGONS %lld %lld\n", (long long)w, (long long)(4 * w));
+  for (long long i = 0; i < (long long)w; ++i) std::fprintf(f, "3 %lld %lld %lld\n", 3 * i, 3 * i + 1, 3 * i + 2);
+  std::fprintf(f, "\n");
+  std::fclose(f);
   return SE_HIP_OK;
 }
 

@@ -62,6 +62,9 @@ EXPORTS = {
     "se_hip_render_depth": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_render_track": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_save_map": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "se_hip_mesh_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "se_hip_mesh_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "se_hip_dump_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
     "se_hip_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "se_hip_download_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "se_hip_download_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -187,6 +190,21 @@ class DenseSLAMPipeline:
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm, self._k(k), mu, frame)))
+
+    def mesh(self) -> np.ndarray:
+        """Marching-cubes triangles of the map, (n, 3, 3) float32 vertices in metres (order unspecified)."""
+        n = C.c_int64()
+        self._check(self.lib.se_hip_mesh_count(self._h, C.byref(n)))
+        out = np.empty((n.value, 3, 3), np.float32)
+        if n.value:
+            w = C.c_int64()
+            self._check(self.lib.se_hip_mesh_download(self._h, out.ctypes.data, n.value, C.byref(w)))
+            out = out[: w.value]
+        return out
+
+    def dump_mesh(self, filename: str):
+        """DenseSLAMSystem::dump_mesh: VTK polydata file."""
+        self._check(self.lib.se_hip_dump_mesh(self._h, filename.encode()))
 
     def filter_depth(self, on: bool = True):
         """preprocessing(..., filterInput): tracking works on the bilateral-filtered depth image."""
