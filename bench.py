@@ -151,6 +151,7 @@ def pmc_traffic(kernel: str, args):
 def main():
     args = parse()
     # OpenMP placement for the CPU baseline leg must be set before libgomp is loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL on this driver stack needs dmabuf IPC (multi-process runs)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
     import torch
