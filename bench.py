@@ -91,6 +91,26 @@ def make_stream(args, n_frames: int = 0):
     return SyntheticStream(args.width, args.height, args.dim, negative_fy=args.icl_like), name
 
 
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of the box from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or logical or 1), (logical or 1)
+
+
 def cpu_baseline(args, n_timed: int):
     """Times the CPU oracle on frames 0..3 (warm-up, executed but excluded as in SURVEY 8(d)) plus
     n_timed frames of the same stream; fps = n / sum(t_integration + t_raycasting)."""
@@ -104,6 +124,9 @@ def cpu_baseline(args, n_timed: int):
     reps = []
     for _ in range(max(1, args.cpu_reps)):
         o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
+        model, physical, logical = host_cpu()
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+        o.lib.so_set_num_threads(max(1, min(physical, avail)))   # OMP_NUM_THREADS = physical cores
         threads = o.lib.so_num_threads()
         s, _ = make_stream(args, 4 + n_timed)
         t_int_sum, t_ray_sum = 0.0, 0.0
@@ -125,6 +148,7 @@ def cpu_baseline(args, n_timed: int):
             "sample": f"frames 4..{3 + n_timed} of the same stream after 4 executed warm-up frames "
                       f"({n_timed} timed frames, median of {len(reps)} repetitions, OpenMP {threads} threads, "
                       f"{'-march=native' if native else '-march=x86-64-v3'} build)",
+            "cpu": f"{model}, {physical} physical cores / {logical} logical CPUs",
             "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed,
             "all_repetitions_fps": [r[0] for r in reps]}
 
