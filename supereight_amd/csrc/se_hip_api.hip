@@ -306,7 +306,7 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
   a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG) * sizeof(uint32_t);
-  const int tiles = ((a.W + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
+  const int tiles = ((a.W + SE_TILE_W - 1) / SE_TILE_W) * ((a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H);
   L.grid = dim3((tiles + 3) / 4);
   return L;
 }

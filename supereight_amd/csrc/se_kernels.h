@@ -6,6 +6,10 @@
 #include "se_device.h"
 
 #define SE_WG 256
+#ifndef SE_TILE_W
+#define SE_TILE_W 8     // raycast: a wave covers a SE_TILE_W x SE_TILE_H pixel tile (product 64)
+#define SE_TILE_H 8
+#endif
 #define SE_SPEC 4     // SDF march: samples fetched per memory round trip
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
 
@@ -1025,9 +1029,9 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
   int vwg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (((nwg & 7) != 0) || !a.xcd_swizzle) vwg = blockIdx.x;
   const int tile = vwg * (SE_WG / 64) + (threadIdx.x >> 6);
-  const int tiles_x = (a.W + 7) >> 3;
-  const int px = ((tile % tiles_x) << 3) + (lane & 7);
-  const int py = a.row_begin + ((tile / tiles_x) << 3) + (lane >> 3);
+  const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W;
+  const int px = (tile % tiles_x) * SE_TILE_W + (lane % SE_TILE_W);
+  const int py = a.row_begin + (tile / tiles_x) * SE_TILE_H + (lane / SE_TILE_W);
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
   if (px < a.W && py < a.row_end) {
     const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
