@@ -305,9 +305,9 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
   // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
   a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
-  L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG) * sizeof(uint32_t);
+  L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles = ((a.W + SE_TILE_W - 1) / SE_TILE_W) * ((a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H);
-  L.grid = dim3((tiles + 3) / 4);
+  L.grid = dim3((tiles + SE_WG_RAY / 64 - 1) / (SE_WG_RAY / 64));
   return L;
 }
 
@@ -641,7 +641,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   if (ov) HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0));
   HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), s));
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
-  const dim3 grid((npix + SE_WG - 1) / SE_WG), block(SE_WG);
+  const dim3 grid((npix + SE_WG_SCAN - 1) / SE_WG_SCAN), block(SE_WG_SCAN);
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
@@ -775,7 +775,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   const RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
   const RayArgs& a = L.a;
   const size_t smem = L.smem;
-  const dim3 grid = L.grid, block(SE_WG);
+  const dim3 grid = L.grid, block(SE_WG_RAY);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   {
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
@@ -958,7 +958,7 @@ int se_hip_render_volume(se_hip_pipeline* p, uint8_t* host_rgbw, const float vie
   for (int i = 0; i < 16; ++i) { const float d = view_cm[i] - p->raycast_pose[i]; d2 += d * d; na += view_cm[i] * view_cm[i]; nb += p->raycast_pose[i] * p->raycast_pose[i]; }
   sh.render = !(d2 <= 1e-5f * 1e-5f * std::min(na, nb)) ? 1 : 0;
   const int tiles = ((L.a.W + 7) / 8) * ((L.a.H + 7) / 8);
-  const dim3 grid((tiles + 3) / 4), block(SE_WG);
+  const dim3 grid((tiles + SE_WG_RAY / 64 - 1) / (SE_WG_RAY / 64)), block(SE_WG_RAY);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   const DevMap& m = p->map;
   if (sdf) { if (m.dense) hipLaunchKernelGGL((k_render_volume<false, true>), grid, block, 0, p->stream, m, L.a, sh, p->vertex, p->normal, p->rgbw);

@@ -5,12 +5,25 @@
 #pragma once
 #include "se_device.h"
 
+#ifndef SE_WG
 #define SE_WG 256
+#endif
+// Workgroup sizes of the two image-space kernels (the LDS staging of the occupancy bits is per
+// workgroup).  Measured on MI355X, 640x480 -> 512^3, same box: raycast 65 / 55.5 / 56.0 us with 64 / 128 / 256
+// threads; the allocation scan is insensitive (37-40 us overlapped).
+#ifndef SE_WG_RAY
+#define SE_WG_RAY 128
+#endif
+#ifndef SE_WG_SCAN
+#define SE_WG_SCAN 128
+#endif
 #ifndef SE_TILE_W
 #define SE_TILE_W 8     // raycast: a wave covers a SE_TILE_W x SE_TILE_H pixel tile (product 64)
 #define SE_TILE_H 8
 #endif
+#ifndef SE_SPEC
 #define SE_SPEC 4     // SDF march: samples fetched per memory round trip
+#endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
 
 // ------------------------------------------------------------------------------------------
@@ -99,9 +112,9 @@ struct AllocArgs {
 // a miss inserts the block (one winner per block), a hit sets VoxelBlock::active_.
 // ------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(SE_WG) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
   const int npix = (a.row_end - a.row_begin) * a.W;
-  const int pid = blockIdx.x * SE_WG + threadIdx.x;
+  const int pid = blockIdx.x * SE_WG_SCAN + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
   if (pid < npix) {
     const int x = pid % a.W;
@@ -146,9 +159,9 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_scan_sdf(DevMap m, const float*
 // three-stage step size; coarse steps insert childless octants at levels leaf-1 / leaf-2.
 // ------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(SE_WG) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
   const int npix = (a.row_end - a.row_begin) * a.W;
-  const int pid = blockIdx.x * SE_WG + threadIdx.x;
+  const int pid = blockIdx.x * SE_WG_SCAN + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
   if (pid < npix) {
     const int x = pid % a.W;
@@ -780,7 +793,7 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   if (1.5f * t_coef.y - t_bias.y > t_min) pos.y = 1.5f;
   if (1.5f * t_coef.z - t_bias.z > t_min) pos.z = 1.5f;
   // a stack slot that was never pushed reads as the first node of its level (code 1 << 3i), t_max 0
-  for (int i = 0; i < a.stack_depth; ++i) { s_par[i * SE_WG + tid] = 1u << (3 * i); s_tmax[i * SE_WG + tid] = 0.f; }
+  for (int i = 0; i < a.stack_depth; ++i) { s_par[i * SE_WG_RAY + tid] = 1u << (3 * i); s_tmax[i * SE_WG_RAY + tid] = 0.f; }
 
   uint32_t gw_index = 0xFFFFFFFFu, gw_word = 0u;  // last occupancy word fetched from global memory (levels between cache and leaf)
   uint32_t leaf_byte = 0u;                        // the 8 leaf-level sibling bits of the current parent
@@ -818,7 +831,7 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
     // descend (ray_iterator.hpp:172-199)
     const float half = scale_exp2 * 0.5f;
     const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
-    if (desc && tc_max < h) { s_par[(22 - scale) * SE_WG + tid] = parent; s_tmax[(22 - scale) * SE_WG + tid] = t_max; }
+    if (desc && tc_max < h) { s_par[(22 - scale) * SE_WG_RAY + tid] = parent; s_tmax[(22 - scale) * SE_WG_RAY + tid] = t_max; }
     const f3 dpos = {pos.x + ((t_center.x > t_min) ? half : 0.f), pos.y + ((t_center.y > t_min) ? half : 0.f), pos.z + ((t_center.z > t_min) ? half : 0.f)};
     // advance_ray (ray_iterator.hpp:116-167)
     const f3 apos = {pos.x - ((t_corner.x <= tc_max) ? scale_exp2 : 0.f), pos.y - ((t_corner.y <= tc_max) ? scale_exp2 : 0.f),
@@ -839,7 +852,7 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
       scale = 31 - __clz(differing_bits);            // == (float_as_int((float)differing_bits) >> 23) - 127, differing_bits < 2^24
       scale_exp2 = __int_as_float((scale - 23 + 127) << 23);
       const int slot = 22 - scale;
-      if (slot >= 0 && slot < a.stack_depth) { parent = s_par[slot * SE_WG + tid]; t_max = s_tmax[slot * SE_WG + tid]; }
+      if (slot >= 0 && slot < a.stack_depth) { parent = s_par[slot * SE_WG_RAY + tid]; t_max = s_tmax[slot * SE_WG_RAY + tid]; }
       if (scale < 23) {
         const uint32_t keep = 0xFFFFFFFFu << scale;
         pos.x = __uint_as_float(__float_as_uint(pos.x) & keep);
@@ -1010,14 +1023,14 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
 template <bool OFUSION, bool STATS, bool DENSE>
-__global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
+__global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
   // LDS: [occupancy words of levels 1..cache_levels][ray stack: parent codes][ray stack: t_max]
   extern __shared__ uint32_t smem[];
   uint32_t* s_occ = smem;
   uint32_t* s_par = smem + a.cache_words;
-  float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG);
+  float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-  for (int i = threadIdx.x; i < a.cache_words; i += SE_WG) s_occ[i] = m.occ[i];
+  for (int i = threadIdx.x; i < a.cache_words; i += SE_WG_RAY) s_occ[i] = m.occ[i];   // (a per-level copy of only the used words was slower)
   __syncthreads();
   const unsigned long long tk1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long tk2 = tk1, tk3 = tk1;
@@ -1028,7 +1041,7 @@ __global__ __launch_bounds__(SE_WG) void k_raycast(DevMap m, RayArgs a, float* _
   const int nwg = gridDim.x, per = (nwg + 7) >> 3;
   int vwg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (((nwg & 7) != 0) || !a.xcd_swizzle) vwg = blockIdx.x;
-  const int tile = vwg * (SE_WG / 64) + (threadIdx.x >> 6);
+  const int tile = vwg * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W;
   const int px = (tile % tiles_x) * SE_TILE_W + (lane % SE_TILE_W);
   const int py = a.row_begin + (tile / tiles_x) * SE_TILE_H + (lane / SE_TILE_W);
@@ -1132,11 +1145,11 @@ struct ShadeArgs { float light[3], ambient[3]; int render; };
 
 // renderVolumeKernel (rendering.cpp:215-283)
 template <bool OFUSION, bool DENSE>
-__global__ __launch_bounds__(SE_WG) void k_render_volume(DevMap m, RayArgs a, ShadeArgs sh, const float* __restrict__ vertex,
+__global__ __launch_bounds__(SE_WG_RAY) void k_render_volume(DevMap m, RayArgs a, ShadeArgs sh, const float* __restrict__ vertex,
                                                          const float* __restrict__ normal, unsigned char* __restrict__ out) {
   const FieldConst fc = se_field_const(m);
   const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * (SE_WG / 64) + (threadIdx.x >> 6);
+  const int tile = blockIdx.x * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
   const int tiles_x = (a.W + 7) >> 3;
   const int px = ((tile % tiles_x) << 3) + (lane & 7);
   const int py = ((tile / tiles_x) << 3) + (lane >> 3);
