@@ -144,13 +144,30 @@ def cpu_baseline(args, n_timed: int):
         reps.append((n_timed / (t_int_sum + t_ray_sum), t_int_sum, t_ray_sum))
     reps.sort()
     fps, t_int_sum, t_ray_sum = reps[len(reps) // 2]          # median repetition
+    # one thread, a shorter sample of the same frames (SURVEY 8d asks for the 1-thread figure beside it)
+    n1 = max(2, min(n_timed, 6))
+    o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
+    o.lib.so_set_num_threads(1)
+    s, _ = make_stream(args, 4 + n1)
+    t1 = 0.0
+    for f in range(4 + n1):
+        d, pose = s.depth(f), s.pose(f)
+        t0 = time.perf_counter()
+        o.integrate(d, pose, s.k, args.mu, f)
+        o.raycast(pose, s.k, args.mu, f)
+        if f >= 4:
+            t1 += time.perf_counter() - t0
+    o.close()
+    o.lib.so_set_num_threads(threads)
+    single = n1 / t1
     return {"value": fps, "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"frames 4..{3 + n_timed} of the same stream after 4 executed warm-up frames "
                       f"({n_timed} timed frames, median of {len(reps)} repetitions, OpenMP {threads} threads, "
                       f"{'-march=native' if native else '-march=x86-64-v3'} build)",
             "cpu": f"{model}, {physical} physical cores / {logical} logical CPUs",
             "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed,
-            "all_repetitions_fps": [r[0] for r in reps]}
+            "all_repetitions_fps": [r[0] for r in reps],
+            "single_thread": {"value": single, "unit": "frames/s", "sample": f"frames 4..{3 + n1}, 1 OpenMP thread"}}
 
 
 def pmc_traffic(kernel: str, args):
