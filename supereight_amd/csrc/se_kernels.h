@@ -667,6 +667,19 @@ __device__ __forceinline__ float se_interp_generic(const DevMap& m, const FieldC
           ((p[4] * (1 - fx) + p[5] * fx) * (1 - fy) + (p[6] * (1 - fx) + p[7] * fx) * fy) * fz);
 }
 
+// Dense grid, sample stencil entirely inside the volume (always, for a point the march can reach): the
+// voxel index (bz << 2l | by << l | bx) * 512 + (x & 7) + 8 (y & 7) + 64 (z & 7) is a sum of one term per axis,
+// so a stencil costs a few integer operations per axis plus two additions per sample instead of a full index
+// computation per sample (the gradient's 32 samples were a quarter of the kernel's vector instructions).
+// Same loads, same arithmetic on the values as the generic forms, which stay the fallback.
+struct AxisTerm { uint32_t blk, loc; };
+__device__ __forceinline__ AxisTerm se_axis_x(int x) { return {(uint32_t)(x >> 3), (uint32_t)(x & 7)}; }
+__device__ __forceinline__ AxisTerm se_axis_y(const DevMap& m, int y) { return {(uint32_t)(y >> 3) << m.leaf_level, (uint32_t)(y & 7) << 3}; }
+__device__ __forceinline__ AxisTerm se_axis_z(const DevMap& m, int z) { return {(uint32_t)(z >> 3) << (2 * m.leaf_level), (uint32_t)(z & 7) << 6}; }
+__device__ __forceinline__ size_t se_axis_index(AxisTerm a, AxisTerm b, AxisTerm c) {
+  return ((size_t)(a.blk + b.blk + c.blk) << 9) + (size_t)(a.loc + b.loc + c.loc);
+}
+
 // Dense grid: the address of every corner of an interpolation cell follows from the position alone, so
 // the SDF march can fetch the corners of a sample together with the sample itself.  Same cell
 // arithmetic as se_interp; the block of corner k is ((lx + (k & 1)) >> 3, ...), the block gather_points
@@ -682,6 +695,14 @@ __device__ __forceinline__ InterpCell se_interp_cell_dense(const DevMap& m, cons
   cell.missing = (cx && cy && cz) ? fc.init_x : fc.empty_x;
   cell.ok = 0u;
   const int nb = m.size >> 3;
+  const int top = m.size - 1;
+  if (lx < top && ly < top && lz < top) {   // the whole cell inside the volume: per-axis terms (see se_axis_index)
+    const AxisTerm X[2] = {se_axis_x(lx), se_axis_x(lx + 1)}, Y[2] = {se_axis_y(m, ly), se_axis_y(m, ly + 1)}, Z[2] = {se_axis_z(m, lz), se_axis_z(m, lz + 1)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vi[k] = se_axis_index(X[k & 1], Y[(k >> 1) & 1], Z[k >> 2]);
+    cell.ok = 0xFFu;
+    return cell;
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int x = lx + (k & 1), y = ly + ((k >> 1) & 1), z = lz + (k >> 2);
@@ -755,19 +776,7 @@ __device__ __forceinline__ f3 se_grad_generic(const DevMap& m, const FieldConst 
   return g;  // the caller applies (0.5f * dim / size)
 }
 
-// Dense grid, sample stencil entirely inside the volume (always, for a point the march can reach): the
-// voxel index (bz << 2l | by << l | bx) * 512 + (x & 7) + 8 (y & 7) + 64 (z & 7) is a sum of one term per axis,
-// so a stencil costs a few integer operations per axis plus two additions per sample instead of a full index
-// computation per sample (the gradient's 32 samples were a quarter of the kernel's vector instructions).
-// Same loads, same arithmetic on the values as the generic forms, which stay the fallback.
-struct AxisTerm { uint32_t blk, loc; };
-__device__ __forceinline__ AxisTerm se_axis_x(int x) { return {(uint32_t)(x >> 3), (uint32_t)(x & 7)}; }
-__device__ __forceinline__ AxisTerm se_axis_y(const DevMap& m, int y) { return {(uint32_t)(y >> 3) << m.leaf_level, (uint32_t)(y & 7) << 3}; }
-__device__ __forceinline__ AxisTerm se_axis_z(const DevMap& m, int z) { return {(uint32_t)(z >> 3) << (2 * m.leaf_level), (uint32_t)(z & 7) << 6}; }
-__device__ __forceinline__ size_t se_axis_index(AxisTerm a, AxisTerm b, AxisTerm c) {
-  return ((size_t)(a.blk + b.blk + c.blk) << 9) + (size_t)(a.loc + b.loc + c.loc);
-}
-
+// Dense-grid forms of interp / grad on the per-axis terms above; the generic forms are the fallback.
 template <bool DENSE>
 __device__ __forceinline__ float se_interp(const DevMap& m, const FieldConst fc, f3 pos, BlkCache& c) {
   if (!DENSE) return se_interp_generic<DENSE>(m, fc, pos, c);
