@@ -125,8 +125,9 @@ def cpu_baseline(args, n_timed: int):
     for _ in range(max(1, args.cpu_reps)):
         o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
         model, physical, logical = host_cpu()
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
-        o.lib.so_set_num_threads(max(1, min(physical, avail)))   # OMP_NUM_THREADS = physical cores
+        # OMP_NUM_THREADS = physical cores, capped by what the OpenMP runtime may use in this container
+        # (not sched_getaffinity: OMP_PROC_BIND has already pinned the calling thread to one core by now)
+        o.lib.so_set_num_threads(max(1, min(physical, o.lib.so_num_threads())))
         threads = o.lib.so_num_threads()
         s, _ = make_stream(args, 4 + n_timed)
         t_int_sum, t_ray_sum = 0.0, 0.0
