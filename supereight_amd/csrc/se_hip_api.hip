@@ -279,6 +279,8 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   RayArgs& a = L.a;
   for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) a.view3[i * 3 + j] = view.m[i][j]; a.org[i] = view.m[i][3]; }
   a.nearp = 0.4f; a.farp = 4.0f;  // constant_parameters.h:22-32
+  a.near_n = a.nearp / m.dim; a.far_n = a.farp / m.dim;
+  for (int i = 0; i < 3; ++i) a.scaled_origin[i] = a.org[i] / m.dim + 1.f;
   a.mu = mu;
   a.step = m.dim / (float)m.size;           // DenseSLAMSystem.cpp:197
   a.largestep = a.step * 8;                 // step * BLOCK_SIDE

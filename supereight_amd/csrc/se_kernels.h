@@ -572,6 +572,8 @@ struct RayArgs {
   float view3[9];  // (pose * K^-1).topLeftCorner<3,3>()
   float org[3];    // its translation column
   float nearp, farp, mu, step, largestep;
+  float near_n, far_n;       // nearp / dim, farp / dim (ray_iterator.hpp:101-102)
+  float scaled_origin[3];    // origin / dim + 1 (ray_iterator.hpp:79)
   float inv_voxel;   // size / dim   (VolumeTemplate, volume_template.hpp:77-102)
   float grad_scale;  // 0.5f * dim / size
   float epsilon;     // exp2f(-log2(size))
@@ -854,7 +856,7 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   d.x = fabsf(direction.x) < eps ? copysignf(eps, direction.x) : direction.x;
   d.y = fabsf(direction.y) < eps ? copysignf(eps, direction.y) : direction.y;
   d.z = fabsf(direction.z) < eps ? copysignf(eps, direction.z) : direction.z;
-  const f3 scaled_origin = f3_add(f3_div(origin, m.dim), {1.f, 1.f, 1.f});
+  const f3 scaled_origin = {a.scaled_origin[0], a.scaled_origin[1], a.scaled_origin[2]};   // origin / dim + 1: the same for every ray, formed on the host
   const f3 t_coef = f3_scale(-1.f, {1.f / fabsf(d.x), 1.f / fabsf(d.y), 1.f / fabsf(d.z)});
   f3 t_bias = f3_mul(t_coef, scaled_origin);
   uint32_t om = 0u;     // octant_mask ^ 7
@@ -864,8 +866,8 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   float t_min = fmaxf(fmaxf(2.0f * t_coef.x - t_bias.x, 2.0f * t_coef.y - t_bias.y), 2.0f * t_coef.z - t_bias.z);
   float t_max = fminf(fminf(t_coef.x - t_bias.x, t_coef.y - t_bias.y), t_coef.z - t_bias.z);
   float h = t_max;
-  t_min = fmaxf(t_min, a.nearp / m.dim);
-  t_max = fminf(t_max, a.farp / m.dim);
+  t_min = fmaxf(t_min, a.near_n);   // nearp / dim
+  t_max = fminf(t_max, a.far_n);    // farp / dim
   const float tmax_m = t_max * m.dim;
   if (1.5f * t_coef.x - t_bias.x > t_min) pos.x = 1.5f;
   if (1.5f * t_coef.y - t_bias.y > t_min) pos.y = 1.5f;
