@@ -104,6 +104,13 @@ int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_
 /* The lists must have been produced by work ordered on the scan stream (se_hip_set_scan_stream) or on the
  * main stream; the call joins the scan stream into the main stream before it reads them. */
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words);
+/* Multi-GPU exchange without a host framework in the per-frame path: `nccl_comm` is the ncclComm_t of the caller's
+ * communicator (RCCL), `nccl_all_gather` the address of ncclAllGather in the RCCL the process has loaded (the library
+ * itself does not link RCCL).  se_hip_alloc_exchange all-gathers the first `words` words of the scan's key list
+ * (se_hip_set_new_keys_buffer / the internal list) into recv_device (world * words) on the scan stream and then does
+ * se_hip_alloc_commit on the gathered lists.  NULL, NULL switches it off. */
+int se_hip_set_exchange(se_hip_pipeline* p, void* nccl_comm, void* nccl_all_gather, int32_t world);
+int se_hip_alloc_exchange(se_hip_pipeline* p, uint64_t* recv_device, int64_t words);
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate,
                            float mu, uint32_t frame);
 

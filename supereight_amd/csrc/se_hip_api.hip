@@ -75,6 +75,10 @@ struct se_hip_pipeline {
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool upload_on_side = false; // the current depth image was uploaded on `side`
   const float* scaled0 = nullptr;   // scaled_depth_[0] of the last se_hip_track
+  // direct RCCL exchange of the key lists (se_hip_set_exchange): the caller's communicator and ncclAllGather
+  void* xcomm = nullptr;
+  int (*xgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int xworld = 0;
   bool mc_table_ready = false;   // SE_MC_TRI uploaded to constant memory
   unsigned long long* mesh_ctr = nullptr;
   bool filter_input = false;   // preprocessing(..., filterInput): tracking sees the bilateral-filtered depth
@@ -700,6 +704,26 @@ int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_
     if (int r = run_zero_chain(p, (const unsigned long long*)device_lists, nlists, (long long)stride_words)) return r;
   HIP_TRY(hipGetLastError());
   return SE_HIP_OK;
+}
+
+int se_hip_set_exchange(se_hip_pipeline* p, void* nccl_comm, void* nccl_all_gather, int32_t world) {
+  if (int r = check(p)) return r;
+  if ((nccl_comm == nullptr) != (nccl_all_gather == nullptr) || (nccl_comm && world < 1)) return fail(SE_HIP_E_INVALID, "bad argument");
+  p->xcomm = nccl_comm;
+  p->xgather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))nccl_all_gather;
+  p->xworld = nccl_comm ? world : 0;
+  return SE_HIP_OK;
+}
+
+int se_hip_alloc_exchange(se_hip_pipeline* p, uint64_t* recv_device, int64_t words) {
+  if (int r = check(p)) return r;
+  if (!p->xgather) return fail(SE_HIP_E_INVALID, "no exchange set (se_hip_set_exchange)");
+  if (!recv_device || words < 2 || (unsigned long long)words > p->map.cap_keys + 1) return fail(SE_HIP_E_INVALID, "bad argument");
+  // on the stream the scan ran on: behind the scan, beside the previous frame's raycast
+  hipStream_t s = (p->overlap && p->side) ? p->side : p->stream;
+  const int rc = p->xgather(p->map.newkeys, recv_device, (size_t)words, /* ncclInt64 */ 4, p->xcomm, s);
+  if (rc != 0) return fail(SE_HIP_E_DEVICE, "ncclAllGather failed with code " + std::to_string(rc));
+  return se_hip_alloc_commit(p, recv_device, p->xworld, words);
 }
 
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {

@@ -98,6 +98,7 @@ class ShardedPipeline:
         self.main = torch.cuda.current_stream(dev)
         self.xs = None
         self._pg = None
+        self.direct = False
         if self.exchange:
             import torch.distributed as dist
             self.gloo = dist.get_backend(group) == "gloo"
@@ -108,7 +109,34 @@ class ShardedPipeline:
             self.p.set_scan_stream(self.xs.cuda_stream)
             pg = group if group is not None else dist.group.WORLD
             self._pg = pg if (not self.gloo and hasattr(pg, "_allgather_base")) else None
+            self.direct = (not self.gloo) and self._direct_rccl(pg, dev)
         self.p.set_stream(self.main.cuda_stream)
+
+    def _direct_rccl(self, pg, dev) -> bool:
+        """Hands the process group's ncclComm_t and the address of ncclAllGather (of the RCCL torch has loaded)
+        to the C library, so that the per-frame exchange is one C call instead of a torch collective
+        (host time per frame 78 -> ~45 us).  Falls back to torch.distributed when torch does not expose them."""
+        import ctypes
+        import os
+        if os.environ.get("SE_EXCHANGE", "") == "torch":
+            return False
+        try:
+            comm = pg._get_backend(dev)._comm_ptr()
+            lib = None
+            for name in ("librccl.so", "librccl.so.1"):
+                path = os.path.join(os.path.dirname(self.torch.__file__), "lib", name)
+                if os.path.exists(path):
+                    lib = ctypes.CDLL(path)
+                    break
+            if lib is None:
+                lib = ctypes.CDLL("librccl.so.1")
+            fn = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value
+            if not comm or not fn:
+                return False
+            self.p.set_exchange(comm, fn, self.world)
+            return True
+        except Exception:
+            return False
 
     def frame(self, depth_ptr: int, pose, k, mu: float, frame: int, integration_rate: int = 1):
         p = self.p
@@ -127,6 +155,11 @@ class ShardedPipeline:
                     host = exchange_key_lists(send.cpu(), self.world, self.group)   # .cpu(): ordered on xs, blocks the host
                     recv.copy_(host)
                     self.main.wait_stream(self.xs)
+                elif self.direct:
+                    p.alloc_exchange(recv.data_ptr(), words)
+                    p.integrate_sweep(k, integration_rate, mu, frame)
+                    p.raycasting(k, mu, frame)
+                    return ran
                 else:
                     if self._pg is not None:
                         self._pg._allgather_base(recv, send).wait()   # wait() = the issuing stream waits, not the host

@@ -50,6 +50,8 @@ EXPORTS = {
     "se_hip_new_keys_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "se_hip_set_new_keys_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "se_hip_alloc_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
+    "se_hip_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "se_hip_alloc_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
@@ -264,6 +266,12 @@ class DenseSLAMPipeline:
 
     def alloc_commit(self, lists_ptr: int, nlists: int, stride_words: int):
         self._check(self.lib.se_hip_alloc_commit(self._h, C.c_void_p(lists_ptr), nlists, stride_words))
+
+    def set_exchange(self, nccl_comm: int, nccl_all_gather: int, world: int):
+        self._check(self.lib.se_hip_set_exchange(self._h, C.c_void_p(nccl_comm), C.c_void_p(nccl_all_gather), world))
+
+    def alloc_exchange(self, recv_ptr: int, words: int):
+        self._check(self.lib.se_hip_alloc_exchange(self._h, C.c_void_p(recv_ptr), words))
 
     def integrate_sweep(self, k, integration_rate: int, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, self._pose_cm, self._k(k),

@@ -64,7 +64,8 @@ def test_sharded_replicas_equal_single(field, mu, R):
     single.close()
 
 
-def test_sharded_pipeline_stream_plan_single_rank_rccl():
+@pytest.mark.parametrize("exchange", ["direct", "torch"])
+def test_sharded_pipeline_stream_plan_single_rank_rccl(exchange, monkeypatch):
     """ShardedPipeline with a one-rank RCCL group: the exchange stream, the all-gather call and the
     commit of the gathered list run exactly as with R > 1 (the own list is committed again, a no-op);
     the result must equal the plain pipeline's."""
@@ -81,7 +82,12 @@ def test_sharded_pipeline_stream_plan_single_rank_rccl():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         single = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+        # "direct": ncclAllGather called by the C library on the process group's communicator;
+        # "torch": torch.distributed's collective (the fallback)
+        if exchange == "torch":
+            monkeypatch.setenv("SE_EXCHANGE", "torch")
         sp = ShardedPipeline((W, H), N, dim, SDF, 0, 1, 0, exchange_always=True)
+        assert sp.direct == (exchange == "direct")
         depth = torch.from_numpy(np.stack([stream.depth(f) for f in range(frames)])).cuda()
         for f in range(frames):
             single.set_depth_device(depth[f].data_ptr()); single.setPose(stream.pose(f))
