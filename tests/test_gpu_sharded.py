@@ -95,6 +95,9 @@ def test_sharded_pipeline_stream_plan_single_rank_rccl(exchange, monkeypatch):
             single.raycasting(stream.k, mu, f)
             sp.frame(depth[f].data_ptr(), stream.pose(f), stream.k, mu, f)
         torch.cuda.synchronize()
+        # the collective really moved the list (committing one's own list again would pass without it)
+        w = sp._words
+        assert torch.equal(sp.recv[:w], sp.send[:w]) and int(sp.send[:w].ne(0).sum()) > 10
         c, x, y, a = single.blocks()
         rc, rx, ry, ra = sp.p.blocks()
         assert len(c) > 500 and rc.shape == c.shape and (rc == c).all() and (ra == a).all()
