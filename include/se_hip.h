@@ -70,6 +70,9 @@ int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
  * all-gather of the key lists is ordered on, so that scan + exchange of frame f+1 hide behind the
  * raycast of frame f.  NULL = a stream owned by the handle (the default). */
 int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
+/* 1 if se_hip_alloc_scan runs on the scan stream (dense replicas, overlap on), 0 if it runs on the main stream like
+ * every other stage -- in which case work ordered with the scan (an all-gather of its list) belongs on the main stream. */
+int se_hip_scan_overlaps(se_hip_pipeline* p);
 
 /* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by
  * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141). */

@@ -83,6 +83,7 @@ struct se_hip_pipeline {
   unsigned long long* mesh_ctr = nullptr;
   bool filter_input = false;   // preprocessing(..., filterInput): tracking sees the bilateral-filtered depth
   bool occ_commit_due = false; // the next sweep kernel must publish the scan's occupancy bits
+  OccLists occ_lists{nullptr, 0, 0};   // ... of these key lists (own list, or every rank's after se_hip_alloc_commit)
   // tracking
   float raycast_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // column-major, pose of the last raycast
   std::vector<float*> pyr_depth, pyr_vertex, pyr_normal;  // level 0 depth aliases the current depth image
@@ -334,6 +335,7 @@ int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
     p->upload_on_side = false;
     HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0));
     p->occ_commit_due = true;
+    if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
     // keys[0] quirk: a row-sharded replica applies it in se_hip_alloc_commit, over every rank's list
     if (p->cfg.field_type == SE_HIP_FIELD_OFUSION && !p->sharded)
       if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r;
@@ -344,7 +346,8 @@ int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
   if (p->occ_commit_due && !fold_into_sweep) {
     p->occ_commit_due = false;
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
-    hipLaunchKernelGGL(k_occ_commit, dim3(64), dim3(SE_WG), 0, p->stream, p->map);
+    hipLaunchKernelGGL(k_occ_commit, dim3(64), dim3(SE_WG), 0, p->stream, p->map, p->occ_lists);
+    p->occ_lists = OccLists{nullptr, 0, 0};
   }
   return SE_HIP_OK;
 }
@@ -536,6 +539,11 @@ int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
   return SE_HIP_OK;
 }
 
+int se_hip_scan_overlaps(se_hip_pipeline* p) {
+  if (int r = check(p)) return r;
+  return p->overlap ? 1 : 0;
+}
+
 int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
   if (int r = check(p)) return r;
   if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
@@ -692,16 +700,30 @@ int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words) {
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
-  // The gathered lists were produced on the scan stream (scan kernel, then the caller's all-gather ordered
-  // behind it): fence that stream here so the caller needs no stream join of its own.
-  if (p->overlap && p->side) { HIP_TRY(hipEventRecord(p->ev_scan, p->side)); HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0)); }
-  if (int r = join_scan(p, true)) return r;   // the sweep that follows publishes the scan's occupancy bits
-  {
+  const unsigned long long* lists = (const unsigned long long*)device_lists;
+  if (p->overlap && p->side) {
+    // The gathered lists were produced on the scan stream (scan kernel, then the caller's all-gather ordered
+    // behind it).  The insertion of the peers' keys stays on that stream -- beside the previous frame's raycast,
+    // off the sweep -> raycast critical path -- and, like the scan, leaves occ[] to the sweep kernel, which
+    // publishes the bits of every gathered list (the own list is one of them).
+    DevMap md = p->map;
+    md.defer_occ = 1;
+    {
+      ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT, p->side);
+      hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->side, md, lists, nlists, (long long)stride_words);
+    }
+    HIP_TRY(hipEventRecord(p->ev_scan, p->side));
+    p->scan_pending = true;
+    p->occ_lists = OccLists{lists, nlists, (long long)stride_words};
+  } else {
+    if (int r = join_scan(p)) return r;
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
-    hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, (const unsigned long long*)device_lists, nlists, (long long)stride_words);
+    hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, lists, nlists, (long long)stride_words);
   }
-  if (p->cfg.field_type == SE_HIP_FIELD_OFUSION)
-    if (int r = run_zero_chain(p, (const unsigned long long*)device_lists, nlists, (long long)stride_words)) return r;
+  if (p->cfg.field_type == SE_HIP_FIELD_OFUSION) {
+    if (int r = join_scan(p, true)) return r;   // the keys[0] chain runs on the main stream, behind scan + commit
+    if (int r = run_zero_chain(p, lists, nlists, (long long)stride_words)) return r;
+  }
   HIP_TRY(hipGetLastError());
   return SE_HIP_OK;
 }
@@ -737,7 +759,9 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   IntegArgs a{};
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) a.debug = std::atoi(ev);
   a.commit_occ = p->occ_commit_due ? 1 : 0;
+  a.occ_lists = p->occ_lists;
   p->occ_commit_due = false;
+  p->occ_lists = OccLists{nullptr, 0, 0};
   // Sophus::SE3f(pose_).inverse() (DenseSLAMSystem.cpp:237): (R^T, R^T * (t * -1)) taken from the matrix
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) a.R[i * 3 + j] = pose.m[j][i];

@@ -243,25 +243,30 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_commit(DevMap m, const unsigned
 // Deferred occupancy update: when the allocation scan of frame f+1 runs concurrently with the raycast
 // of frame f it inserts into tab[] / the lists but leaves occ[] (which that raycast is walking)
 // alone; this kernel then sets the bits of every inserted octant and of all its ancestors.
-__device__ __forceinline__ void se_occ_commit(const DevMap& m) {
-  unsigned long long n = m.newkeys[0];
-  if (n > m.cap_keys) n = m.cap_keys;
-  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-    const unsigned long long raw = m.newkeys[1 + i];
-    if (raw & SE_KEY_ACTIVATE) continue;
-    const int level = (int)(raw & 0x1FFull);
-    if (level < 1 || level > m.leaf_level) continue;
-    const unsigned long long code = raw & ~0x1FFull;
-    const int sh = m.max_level - level;
-    int x = (int)(se_compact21(code) >> sh), y = (int)(se_compact21(code >> 1) >> sh), z = (int)(se_compact21(code >> 2) >> sh);
-    for (int l = level; l >= 1; --l) {
-      const uint32_t c = occ_code(l, x, y, z);
-      atomicOr(&m.occ[c >> 5], 1u << (c & 31u));
-      x >>= 1; y >>= 1; z >>= 1;
+struct OccLists { const unsigned long long* lists; int nlists; long long stride_words; };   // [count, keys...] per list
+__device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L) {
+  for (int li = 0; li < L.nlists; ++li) {
+    const unsigned long long* list = L.lists + (long long)li * L.stride_words;
+    unsigned long long n = list[0];
+    if (n > (unsigned long long)(L.stride_words - 1)) n = (unsigned long long)(L.stride_words - 1);
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+      const unsigned long long raw = list[1 + i];
+      if (raw & SE_KEY_ACTIVATE) continue;
+      const int level = (int)(raw & 0x1FFull);
+      if (level < 1 || level > m.leaf_level) continue;
+      const unsigned long long code = raw & ~0x1FFull;
+      const int sh = m.max_level - level;
+      int x = (int)(se_compact21(code) >> sh), y = (int)(se_compact21(code >> 1) >> sh), z = (int)(se_compact21(code >> 2) >> sh);
+      if ((unsigned)x >= (1u << level) || (unsigned)y >= (1u << level) || (unsigned)z >= (1u << level)) continue;
+      for (int l = level; l >= 1; --l) {
+        const uint32_t c = occ_code(l, x, y, z);
+        atomicOr(&m.occ[c >> 5], 1u << (c & 31u));
+        x >>= 1; y >>= 1; z >>= 1;
+      }
     }
   }
 }
-__global__ __launch_bounds__(SE_WG) void k_occ_commit(DevMap m) { se_occ_commit(m); }
+__global__ __launch_bounds__(SE_WG) void k_occ_commit(DevMap m, OccLists L) { se_occ_commit(m, L); }
 
 // unique_multiscale keeps keys[0] whatever its level (se_core/include/se/algorithms/unique.hpp:64-79):
 // when the smallest key of a frame's list (after filter_ancestors) is a coarse octant, the
@@ -335,7 +340,8 @@ struct IntegArgs {
   int W, H;
   const float* bspline;    // OFusion: 1000-entry B-spline CDF table
   const float* logodds;    // OFusion: log2f(s/(1-s)) for every (Q1 index, Q2 index) pair, see se_hip_api.hip
-  int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan first
+  int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan / commit first
+  OccLists occ_lists;      // the key lists whose insertions are published
   int debug;               // diagnostic: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
   uint32_t* ctr_mirror;    // pinned host copy of ctr[] (launch-geometry estimate of the next sweep), may be null
 };
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   // counters as this sweep sees them -> pinned host memory (posted write; sizes the next sweep's grid
   // without a device-to-host copy between this kernel and the raycast)
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
-  if (a.commit_occ) se_occ_commit(m);   // nothing in this kernel reads occ[]; the raycast that follows does
+  if (a.commit_occ) se_occ_commit(m, a.occ_lists);   // nothing in this kernel reads occ[]; the raycast that follows does
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;

@@ -105,8 +105,11 @@ class ShardedPipeline:
             # scan + collective are ordered on the stream that is current now (the collective is issued
             # without a stream context switch per frame); the sweep and the raycast get a stream of their own
             self.xs = torch.cuda.current_stream(dev)
-            self.main = torch.cuda.Stream(dev)
-            self.p.set_scan_stream(self.xs.cuda_stream)
+            if self.p.scan_overlaps():
+                self.main = torch.cuda.Stream(dev)
+                self.p.set_scan_stream(self.xs.cuda_stream)
+            # else (pooled bricks / overlap switched off): the scan runs on the main stream, so everything,
+            # the collective included, is ordered on the one current stream
             pg = group if group is not None else dist.group.WORLD
             self._pg = pg if (not self.gloo and hasattr(pg, "_allgather_base")) else None
             self.direct = (not self.gloo) and self._direct_rccl(pg, dev)
@@ -154,7 +157,6 @@ class ShardedPipeline:
                     # dry-run transport (several ranks sharing one GPU, no RCCL): stage through the host
                     host = exchange_key_lists(send.cpu(), self.world, self.group)   # .cpu(): ordered on xs, blocks the host
                     recv.copy_(host)
-                    self.main.wait_stream(self.xs)
                 elif self.direct:
                     p.alloc_exchange(recv.data_ptr(), words)
                     p.integrate_sweep(k, integration_rate, mu, frame)

@@ -42,6 +42,7 @@ EXPORTS = {
     "se_hip_sync": (C.c_int, [C.c_void_p]),
     "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "se_hip_scan_overlaps": (C.c_int, [C.c_void_p]),
     "se_hip_upload_depth": (C.c_int, [C.c_void_p, _f32p]),
     "se_hip_upload_depth_mm": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     "se_hip_set_depth_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -158,6 +159,9 @@ class DenseSLAMPipeline:
 
     def set_stream(self, hip_stream_ptr: int):
         self._check(self.lib.se_hip_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def scan_overlaps(self) -> bool:
+        return bool(self._check(self.lib.se_hip_scan_overlaps(self._h)))
 
     def set_scan_stream(self, hip_stream_ptr: int):
         self._check(self.lib.se_hip_set_scan_stream(self._h, C.c_void_p(hip_stream_ptr)))
