@@ -136,7 +136,8 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 hipEvent_t get_event(se_hip_pipeline* p) {
   if (!p->event_pool.empty()) { hipEvent_t e = p->event_pool.back(); p->event_pool.pop_back(); return e; }
   hipEvent_t e;
-  hipEventCreate(&e);
+  // timing only: without the system-scope fence a record would otherwise put between the kernels it brackets
+  hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
   return e;
 }
 struct ScopedTimer {
@@ -432,8 +433,10 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
   if (e != hipSuccess) return bail(e, "hipStreamCreate");
   p->own_side = true;
-  hipEventCreateWithFlags(&p->ev_sweep, hipEventDisableTiming);
-  hipEventCreateWithFlags(&p->ev_scan, hipEventDisableTiming);
+  // these two only order streams of this device against each other: no system-scope fence (its cache write-back /
+  // invalidate sits between the sweep and the raycast otherwise), no timing
+  hipEventCreateWithFlags(&p->ev_sweep, hipEventDisableTiming | hipEventDisableSystemFence);
+  hipEventCreateWithFlags(&p->ev_scan, hipEventDisableTiming | hipEventDisableSystemFence);
   p->sharded = (p->row_begin != 0 || p->row_end != cfg->height);
   p->overlap = dense && !std::getenv("SE_HIP_NO_OVERLAP");
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
