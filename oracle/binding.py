@@ -22,14 +22,15 @@ c_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 c_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 
-def build(native: bool = False, force: bool = False) -> str:
-    """(Re)build the oracle shared library with oracle/Makefile; returns its path."""
-    out = "libse_oracle_native.so" if native else "libse_oracle.so"
+def build(native: bool = False, force: bool = False, fma: bool = False) -> str:
+    """(Re)build the oracle shared library with oracle/Makefile; returns its path.
+    fma=True: the noise-floor variant compiled with -ffp-contract=fast (see oracle/Makefile)."""
+    out = "libse_oracle_fma.so" if fma else ("libse_oracle_native.so" if native else "libse_oracle.so")
     path = os.path.join(_HERE, out)
     src = os.path.join(_HERE, "se_oracle.cpp")
     stale = (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src)
     if force or stale:
-        args = ["make", "-C", _HERE, f"OUT={out}"] + (["ARCH=native"] if native else [])
+        args = ["make", "-C", _HERE, f"OUT={out}"] + (["FPC=fast"] if fma else (["ARCH=native"] if native else []))
         if force:
             args.insert(1, "-B")
         subprocess.run(args, check=True, capture_output=True)
@@ -108,6 +109,8 @@ def _declare(lib):
         "so_pipe_mesh": (C.c_longlong, [vp, C.c_void_p, C.c_longlong]),
         "so_num_threads": (i32, []),
         "so_set_num_threads": (None, [i32]),
+        "so_set_sophus_quat": (None, [i32]),
+        "so_fp_contract": (i32, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -116,14 +119,14 @@ def _declare(lib):
     return lib
 
 
-def load(native: bool = False):
-    key = "native" if native else "portable"
+def load(native: bool = False, fma: bool = False):
+    key = "fma" if fma else ("native" if native else "portable")
     if key not in _LIBS:
         try:
-            path = build(native=native)
+            path = build(native=native, fma=fma)
             lib = C.CDLL(path)
         except (OSError, subprocess.CalledProcessError):
-            path = build(native=native, force=True)
+            path = build(native=native, force=True, fma=fma)
             lib = C.CDLL(path)
         _LIBS[key] = _declare(lib)
     return _LIBS[key]
@@ -136,8 +139,8 @@ STAT_NAMES = ("probes", "keys_emitted", "swept", "nodes", "gets", "interps", "gr
 class OraclePipeline:
     """The reference's DenseSLAMSystem::integration / ::raycasting on the CPU oracle."""
 
-    def __init__(self, field: int, size: int, dim: float, width: int, height: int, native: bool = False):
-        self.lib = load(native)
+    def __init__(self, field: int, size: int, dim: float, width: int, height: int, native: bool = False, fma: bool = False):
+        self.lib = load(native, fma)
         self.field, self.size, self.dim, self.W, self.H = field, size, float(dim), width, height
         self.h = self.lib.so_pipe_create(field, size, dim, width, height)
 

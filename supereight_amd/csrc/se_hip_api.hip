@@ -127,6 +127,15 @@ struct se_hip_pipeline {
   int64_t launches[SE_HIP_K_COUNT] = {0};
   int row_begin = 0, row_end = 0;
   int integ_grid = 0;  // > 0: fixed number of workgroups for the integration sweep (tuning knob)
+  unsigned short* tile_cost = nullptr;   // raycast scheduling hint: per wave tile, cost in the previous launch (see RayArgs)
+  int* prio_thr = nullptr;               // its three priority thresholds (device; written by the integration sweep)
+  bool prio_hint = true;                 // SE_HIP_PRIO=0 switches the hint off
+  int xcd_swizzle = 0; // raycast: supertile edge (in 8x8-pixel wave tiles) of the XCD-aware workgroup -> tile mapping; 0 = row-major
+#ifdef SE_DIAG
+  uint32_t* diag_pix = nullptr;   // diagnostic build: per-pixel / per-wave raycast records (se_hip_diag_*)
+  uint32_t* diag_wave = nullptr;
+  int debug_integ = 0;
+#endif
 };
 
 namespace {
@@ -295,10 +304,14 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.epsilon = exp2f(-(float)p->max_level);  // ray_iterator.hpp:63
   a.min_scale = 23 - p->leaf_level;         // ray_iterator.hpp:62
   a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_ROWS")) {  // diagnostic: raycast only rows [b,e)
+#ifdef SE_DIAG
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_ROWS")) {  // diagnostic build: raycast only rows [b,e)
     int b = 0, e = 0;
     if (std::sscanf(ev, "%d,%d", &b, &e) == 2 && b >= 0 && e > b && e <= a.H) { a.row_begin = b; a.row_end = e; }
   }
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
+  a.diag_pix = p->diag_pix; a.diag_wave = p->diag_wave;
+#endif
   // occupancy levels staged in LDS: levels 1..5 (4.7 KB; measured: level 6 = +32 KB costs more
   // occupancy and staging time than the leaf-level bit tests it saves) unless overridden
   int cl = p->ray_cache_levels >= 0 ? p->ray_cache_levels : 5;
@@ -309,13 +322,20 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.cache_codes = 2u << (3 * cl);
   a.has_deep = cl < p->leaf_level - 1 ? 1 : 0;
   a.stack_depth = p->leaf_level;
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
-  // measured on MI355X: banding the image per XCD (b % 8 dispatch) is slower (58 -> 63 us) than the
-  // default round-robin, which balances cheap and expensive image regions across XCDs; kept as a knob
-  a.xcd_swizzle = std::getenv("SE_HIP_XCD_SWIZZLE") ? 1 : 0;
+  a.tile_cost = p->prio_hint ? p->tile_cost : nullptr;
+  a.prio_thr = p->prio_thr;
+  // workgroup -> tile mapping: supertiles of S x S wave tiles dealt round-robin to the 8 XCDs (see k_raycast)
+  a.xcd_swizzle = p->xcd_swizzle;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
-  const int tiles = ((a.W + SE_TILE_W - 1) / SE_TILE_W) * ((a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H);
-  L.grid = dim3((tiles + SE_WG_RAY / 64 - 1) / (SE_WG_RAY / 64));
+  const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
+  if (a.xcd_swizzle > 1) {
+    const int S = a.xcd_swizzle;
+    const int n_st = ((tiles_x + S - 1) / S) * ((tiles_y + S - 1) / S);
+    L.grid = dim3((unsigned)(((n_st + 7) / 8) * 8 * (S * S / (SE_WG_RAY / 64))));
+  } else {
+    a.xcd_swizzle = 0;
+    L.grid = dim3((tiles_x * tiles_y + SE_WG_RAY / 64 - 1) / (SE_WG_RAY / 64));
+  }
   return L;
 }
 
@@ -395,6 +415,12 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_XCD_SWIZZLE")) p->xcd_swizzle = std::atoi(ev);          // tuning knob (0, 2, 4, 8: supertile edge)
+  if (p->xcd_swizzle < 2 || (p->xcd_swizzle & (p->xcd_swizzle - 1)) || p->xcd_swizzle > 16) p->xcd_swizzle = 0;
+#ifdef SE_DIAG
+  if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
+#endif
+  if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
   p->max_level = ilog2(N);
   p->leaf_level = p->max_level - 3;
   DevMap& m = p->map;
@@ -441,10 +467,11 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->overlap = dense && !std::getenv("SE_HIP_NO_OVERLAP");
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
+  ALLOC(m.lbits, ((cells + 31) / 32) * sizeof(uint32_t));
   ALLOC(m.vx, slots * 512 * sizeof(float));
   ALLOC(m.vy, slots * 512 * sizeof(float));
   ALLOC(m.bpos, cap * sizeof(uint32_t));
-  ALLOC(m.bactive, slots);
+  ALLOC(m.bactive, (slots + 3) & ~(size_t)3);   // whole 32-bit words: se_set_active_once
   ALLOC(m.nx, capn * 8 * sizeof(float));
   ALLOC(m.ny, capn * 8 * sizeof(float));
   ALLOC(m.npos, capn * sizeof(uint32_t));
@@ -457,12 +484,18 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(p->vertex, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   ALLOC(p->normal, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   ALLOC(p->chain, 4 * sizeof(unsigned long long));
+  const size_t n_tiles = ((size_t)(cfg->width + SE_TILE_W - 1) / SE_TILE_W) * ((size_t)(cfg->height + SE_TILE_H - 1) / SE_TILE_H);
+  ALLOC(p->tile_cost, n_tiles * sizeof(unsigned short));
+  ALLOC(p->prio_thr, 4 * sizeof(int));
+  hipMemsetAsync(p->tile_cost, 0, n_tiles * sizeof(unsigned short), p->stream);
+  { const int off[4] = {256, 256, 256, 0}; hipMemcpyAsync(p->prio_thr, off, sizeof off, hipMemcpyHostToDevice, p->stream); }
   p->depth = p->depth_own;
   e = hipHostMalloc((void**)&p->ctr_host, C_COUNT * sizeof(uint32_t));
   if (e != hipSuccess) return bail(e, "hipHostMalloc");
 
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.lbits, 0, ((cells + 31) / 32) * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, cap * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, slots, p->stream);
   hipMemsetAsync(m.npos, 0, capn * sizeof(uint32_t), p->stream);
@@ -503,8 +536,8 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
-                  p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain};
+  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
+                  p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
   for (auto* q : p->pyr_vertex) if (q) hipFree(q);
@@ -662,8 +695,19 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
-      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_sdf<true>, grid, block, 0, s, ms, p->depth, a);
-      else hipLaunchKernelGGL(k_alloc_scan_sdf<false>, grid, block, 0, s, ms, p->depth, a);
+#if SE_SCAN_TILED
+      const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
+      const dim3 sgrid((tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
+#else
+      const dim3 sgrid = grid;
+#endif
+      if (m.dense) {
+        if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, true>), sgrid, block, 0, s, ms, p->depth, a);
+        else hipLaunchKernelGGL((k_alloc_scan_sdf<false, true>), sgrid, block, 0, s, ms, p->depth, a);
+      } else {
+        if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, false>), sgrid, block, 0, s, ms, p->depth, a);
+        else hipLaunchKernelGGL((k_alloc_scan_sdf<false, false>), sgrid, block, 0, s, ms, p->depth, a);
+      }
     } else {
       if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
       else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
@@ -760,7 +804,9 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   const M4 pose = from_colmajor(pose_cm);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   IntegArgs a{};
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) a.debug = std::atoi(ev);
+#ifdef SE_DIAG
+  a.debug = p->debug_integ;
+#endif
   a.commit_occ = p->occ_commit_due ? 1 : 0;
   a.occ_lists = p->occ_lists;
   p->occ_commit_due = false;
@@ -789,6 +835,10 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   a.W = p->cfg.width; a.H = p->cfg.height;
   a.bspline = p->bspline; a.logodds = p->logodds;
   a.ctr_mirror = p->ctr_host;   // the kernel refreshes the host copy of the counters (next frame's launch geometry)
+  if (p->prio_hint) {
+    a.tile_cost = p->tile_cost; a.prio_thr = p->prio_thr;
+    a.n_tiles = ((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H);
+  }
   const dim3 block(SE_WG);
   {
     // one launch: blocks (one wave each) then nodes.  The block count lives on the device; the grid is
@@ -832,17 +882,18 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   {
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
-#define SE_RAY(OF, ST, DN) hipLaunchKernelGGL((k_raycast<OF, ST, DN>), grid, block, smem, p->stream, m, a, p->vertex, p->normal)
+#define SE_RAY(OF, ST, DN, SH) hipLaunchKernelGGL((k_raycast<OF, ST, DN, SH>), grid, block, smem, p->stream, m, a, p->vertex, p->normal)
+    const bool shallow = !a.has_deep;   // every non-leaf occupancy level is in LDS (volumes <= 512^3): specialised traversal loop
     const int variant = (sdf ? 0 : 4) | (p->stats ? 2 : 0) | (m.dense ? 1 : 0);
     switch (variant) {
-      case 0: SE_RAY(false, false, false); break;
-      case 1: SE_RAY(false, false, true); break;
-      case 2: SE_RAY(false, true, false); break;
-      case 3: SE_RAY(false, true, true); break;
-      case 4: SE_RAY(true, false, false); break;
-      case 5: SE_RAY(true, false, true); break;
-      case 6: SE_RAY(true, true, false); break;
-      case 7: SE_RAY(true, true, true); break;
+      case 0: if (shallow) SE_RAY(false, false, false, true); else SE_RAY(false, false, false, false); break;
+      case 1: if (shallow) SE_RAY(false, false, true, true); else SE_RAY(false, false, true, false); break;
+      case 2: SE_RAY(false, true, false, false); break;
+      case 3: SE_RAY(false, true, true, false); break;
+      case 4: if (shallow) SE_RAY(true, false, false, true); else SE_RAY(true, false, false, false); break;
+      case 5: if (shallow) SE_RAY(true, false, true, true); else SE_RAY(true, false, true, false); break;
+      case 6: SE_RAY(true, true, false, false); break;
+      case 7: SE_RAY(true, true, true, false); break;
     }
 #undef SE_RAY
   }
@@ -1059,7 +1110,9 @@ namespace {
 int run_mesh(se_hip_pipeline* p, float* dev_out, unsigned long long capacity, unsigned long long* n) {
   if (int r = join_scan(p)) return r;
   if (!p->mc_table_ready) {
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(SE_MC_TRI), SE_MC_TRI_INIT, sizeof(SE_MC_TRI_INIT)));
+    signed char table[256][SE_MC_WIDTH];
+    se_mc_expand(table);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(SE_MC_TRI), table, sizeof(table)));
     p->mc_table_ready = true;
   }
   if (!p->mesh_ctr) HIP_TRY(hipMalloc((void**)&p->mesh_ctr, 2 * sizeof(unsigned long long)));
@@ -1297,5 +1350,29 @@ int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[16], int32_t reset) {
   if (reset) HIP_TRY(hipMemsetAsync(p->map.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream));
   return SE_HIP_OK;
 }
+
+#ifdef SE_DIAG
+// Diagnostic build only (tools/): per-pixel and per-wave records of the STATS raycast variants.
+int se_hip_diag_enable(se_hip_pipeline* p, int32_t on) {
+  if (int r = check(p)) return r;
+  const size_t npix = (size_t)p->cfg.width * p->cfg.height, nwave = ((size_t)(p->cfg.width + 7) / 8) * ((size_t)(p->cfg.height + 7) / 8);
+  if (on && !p->diag_pix) {
+    HIP_TRY(hipMalloc((void**)&p->diag_pix, npix * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&p->diag_wave, nwave * 8 * sizeof(uint32_t)));
+  }
+  if (!on) { if (p->diag_pix) hipFree(p->diag_pix); if (p->diag_wave) hipFree(p->diag_wave); p->diag_pix = p->diag_wave = nullptr; }
+  if (p->diag_pix) { HIP_TRY(hipMemset(p->diag_pix, 0, npix * sizeof(uint32_t))); HIP_TRY(hipMemset(p->diag_wave, 0, nwave * 8 * sizeof(uint32_t))); }
+  return SE_HIP_OK;
+}
+int se_hip_diag_download(se_hip_pipeline* p, uint32_t* pix, uint32_t* wave) {
+  if (int r = check(p)) return r;
+  if (!p->diag_pix) return fail(SE_HIP_E_INVALID, "se_hip_diag_enable first");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  const size_t npix = (size_t)p->cfg.width * p->cfg.height, nwave = ((size_t)(p->cfg.width + 7) / 8) * ((size_t)(p->cfg.height + 7) / 8);
+  if (pix) HIP_TRY(hipMemcpy(pix, p->diag_pix, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (wave) HIP_TRY(hipMemcpy(wave, p->diag_wave, nwave * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return SE_HIP_OK;
+}
+#endif
 
 }  // extern "C"

@@ -25,6 +25,10 @@
 #define SE_SPEC 2     // SDF march: samples fetched per memory round trip (measured 1 / 2 / 3 / 4: 51.3 / 50.3 / 50.0 / 51.6 us at 512^3, 81 / 77 / 78 / 82 us at 1024^3)
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
+#ifndef SE_RUN
+#define SE_RUN 0      // SDF march: blocks probed ahead in the leaf bitmap while the ray moves in largesteps (0 = off; 6 cuts the longest
+                      // march from 23 to 17 round trips but the launch got 9 us SLOWER at 512^3 -- measured r02, kept as an experiment)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // index insertion (replaces Octree::allocate / allocate_level, se_core/include/se/octree.hpp:792-856)
@@ -59,6 +63,8 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
     const uint32_t slot = block_slot(m, idx, bp);
     m.bpos[idx] = bp;
     m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
+    const uint32_t lin = block_linear(m, x, y, z);
+    atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u));
     occ_set(m, level, x, y, z);
     atomicExch(e, slot + 1u);
   } else {
@@ -81,9 +87,15 @@ __device__ __forceinline__ void se_append_key(const DevMap& m, int level, int x,
 }
 // n->active(true) of the allocation scans.  A row-sharded replica only sees its own rays, so a block
 // it switches from inactive to active is also reported to the peers (which cannot see that ray).
+__device__ __forceinline__ bool se_set_active_once(const DevMap& m, uint32_t slot) {
+  // one winner per block: the thread that flips the byte from 0 (bytes are only ever written whole, by this scan and by the sweep)
+  uint32_t* w = (uint32_t*)m.bactive + (slot >> 2);
+  const uint32_t bit = 1u << (8u * (slot & 3u));
+  return (atomicOr(w, bit) & (0xFFu << (8u * (slot & 3u)))) == 0u;
+}
 __device__ __forceinline__ void se_mark_active(const DevMap& m, uint32_t slot, bool sharded, int bx, int by, int bz) {
-  if (sharded && m.bactive[slot] == 0) se_append_key(m, m.leaf_level, bx, by, bz, SE_KEY_ACTIVATE);
-  m.bactive[slot] = 1;
+  if (sharded) { if (se_set_active_once(m, slot)) se_append_key(m, m.leaf_level, bx, by, bz, SE_KEY_ACTIVATE); }   // one key per block, not one per ray
+  else m.bactive[slot] = 1;
 }
 
 template <bool STATS> __device__ __forceinline__ void se_stat_add(const DevMap& m, int which, unsigned long long v) {
@@ -108,17 +120,84 @@ struct AllocArgs {
 
 // ------------------------------------------------------------------------------------------
 // SDF allocation scan: buildAllocationList (se_denseslam/src/kfusion/alloc_impl.hpp:54-118)
-// fused with Octree::allocate.  One thread per pixel; every band step probes the leaf grid;
-// a miss inserts the block (one winner per block), a hit sets VoxelBlock::active_.
+// fused with Octree::allocate.  One thread per pixel; every band step is classified by the block it
+// falls into; a block that does not exist is inserted (one winner per block), one that does gets
+// VoxelBlock::active_ set.
+//
+// In steady state 6.6 M band steps find ~40 new blocks, and all but a handful of the blocks they cross
+// are already active (the previous sweep left every visible block active), so the kernel is organised
+// around that: pass 1 walks the band with the reference's float arithmetic and only records the
+// distinct blocks in LDS (no memory access, no branch on memory); pass 2 fetches the `active` bytes of
+// all of them in one round trip (dense bricks: the flag's index is the block's grid index, no look-up)
+// and goes to the index only for the few that are not active yet.  The result -- block set, active
+// flags, key list as a set -- is what probing the index at every step gives.
 // ------------------------------------------------------------------------------------------
-template <bool STATS>
+#ifndef SE_SCAN_SLOTS
+#define SE_SCAN_SLOTS 8     // distinct blocks of one ray buffered before their flags are fetched
+#endif
+#ifndef SE_SCAN_TILED
+#define SE_SCAN_TILED 1     // a wave scans an 8x8 pixel tile (its rays cross the same 1-2 blocks) instead of 64 pixels of a row
+#endif
+template <bool STATS, bool DENSE>
+__device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& a, const uint32_t* s_blk, int nb, unsigned long long& newk) {
+  const int L = m.leaf_level;
+  const uint32_t mask = (1u << L) - 1u;
+  uint32_t lin[SE_SCAN_SLOTS];
+  uint32_t val[SE_SCAN_SLOTS];
+#pragma unroll
+  for (int k = 0; k < SE_SCAN_SLOTS; ++k) lin[k] = s_blk[k * SE_WG_SCAN];
+#pragma unroll
+  for (int k = 0; k < SE_SCAN_SLOTS; ++k) {
+    const uint32_t l = k < nb ? lin[k] : lin[0];
+    val[k] = DENSE ? (uint32_t)m.bactive[l] : m.tab[m.leaf_off + l];   // dense: active flag; pooled: index entry
+  }
+#pragma unroll
+  for (int k = 0; k < SE_SCAN_SLOTS; ++k) {
+    if (k >= nb) continue;
+    const int bx = (int)(lin[k] & mask), by = (int)((lin[k] >> L) & mask), bz = (int)(lin[k] >> (2 * L));
+    uint32_t e;
+    if (DENSE) {
+      if (val[k]) continue;                        // exists and is active already
+      e = m.tab[m.leaf_off + lin[k]];
+    } else {
+      e = val[k];
+    }
+    if (e == 0u) {
+      if (se_insert_octant(m, L, bx, by, bz)) { se_append_key(m, L, bx, by, bz); ++newk; }
+    } else if (e != SE_PENDING) {
+      // n->active(true), alloc_impl.hpp:109.  A row-sharded replica only sees its own rays, so a block it
+      // switches from inactive to active is also reported to the peers -- once, by the thread that flipped it.
+      if (a.sharded) { if (se_set_active_once(m, e - 1u)) se_append_key(m, L, bx, by, bz, SE_KEY_ACTIVATE); }
+      else m.bactive[e - 1u] = 1;
+    }
+  }
+}
+template <bool STATS, bool DENSE>
 __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
-  const int npix = (a.row_end - a.row_begin) * a.W;
-  const int pid = blockIdx.x * SE_WG_SCAN + threadIdx.x;
+  __shared__ uint32_t s_blk_all[SE_SCAN_SLOTS * SE_WG_SCAN];
+  uint32_t* s_blk = s_blk_all + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
-  if (pid < npix) {
-    const int x = pid % a.W;
-    const int y = a.row_begin + pid / a.W;
+  int x, y;
+  bool in_image;
+#if SE_SCAN_TILED
+  {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
+    const int tiles_x = (a.W + 7) >> 3;
+    x = (tile % tiles_x) * 8 + (lane & 7);
+    y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
+    in_image = x < a.W && y < a.row_end;
+  }
+#else
+  {
+    const int npix = (a.row_end - a.row_begin) * a.W;
+    const int pid = blockIdx.x * SE_WG_SCAN + threadIdx.x;
+    x = pid % a.W;
+    y = a.row_begin + pid / a.W;
+    in_image = pid < npix;
+  }
+#endif
+  if (in_image) {
     const float depth = depthmap[x + y * a.W];
     if (!(depth == 0)) {
       const f3 worldVertex = m34_mul_h(a.kpose, {(x + 0.5f) * depth, (y + 0.5f) * depth, depth});
@@ -128,25 +207,24 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
       const f3 step = f3_div(f3_scale_r(direction, a.band), (float)a.num_steps);
       f3 voxelPos = origin;
       const float fsize = (float)m.size;
-      int lbx = -1, lby = -1, lbz = -1;  // last block handled (probing it again changes nothing)
+      uint32_t last = 0xFFFFFFFFu;   // last block recorded (probing it again changes nothing)
+      int nb = 0;
       for (int i = 0; i < a.num_steps; ++i) {
         const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
         const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
         if ((vx < fsize) && (vy < fsize) && (vz < fsize) && (vx >= 0) && (vy >= 0) && (vz >= 0)) {
-          const int bx = (int)vx >> 3, by = (int)vy >> 3, bz = (int)vz >> 3;
           ++probes;
-          if (bx != lbx || by != lby || bz != lbz) {
-            lbx = bx; lby = by; lbz = bz;
-            const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
-            if (e == 0u) {
-              if (se_insert_octant(m, m.leaf_level, bx, by, bz)) { se_append_key(m, m.leaf_level, bx, by, bz); ++newk; }
-            } else if (e != SE_PENDING) {
-              se_mark_active(m, e - 1u, a.sharded != 0, bx, by, bz);  // n->active(true), alloc_impl.hpp:109
-            }
+          const uint32_t lin = block_linear(m, (int)vx >> 3, (int)vy >> 3, (int)vz >> 3);
+          if (lin != last) {
+            last = lin;
+            if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
+            s_blk[nb * SE_WG_SCAN] = lin;
+            ++nb;
           }
         }
         voxelPos = f3_add(voxelPos, step);
       }
+      if (nb) se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk);
     }
   }
   se_stat_add<STATS>(m, S_PROBES, probes);
@@ -342,9 +420,35 @@ struct IntegArgs {
   const float* logodds;    // OFusion: log2f(s/(1-s)) for every (Q1 index, Q2 index) pair, see se_hip_api.hip
   int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan / commit first
   OccLists occ_lists;      // the key lists whose insertions are published
-  int debug;               // diagnostic: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
+#ifdef SE_DIAG
+  int debug;               // diagnostic build only: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
+#endif
   uint32_t* ctr_mirror;    // pinned host copy of ctr[] (launch-geometry estimate of the next sweep), may be null
+  // raycast scheduling hint (see RayArgs::tile_cost): this launch also turns the previous raycast's per-tile costs into
+  // the three priority thresholds of the next one (top 20 % / 7 % / 2.5 % of the tiles); null = hint off
+  const unsigned short* tile_cost;
+  int n_tiles;
+  int* prio_thr;
 };
+
+// One workgroup: 256-bin histogram of the tile costs, thresholds = smallest cost v with #(cost >= v) <= fraction * n.
+__device__ __forceinline__ void se_prio_thresholds(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist) {
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[min((int)cost[i], 255)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned lim[3] = {(unsigned)n / 5u, (unsigned)(n * 7) / 100u, (unsigned)n / 40u};
+    int t[3] = {256, 256, 256};
+    unsigned acc = 0u;
+    for (int v = 255; v >= 1; --v) {
+      acc += hist[v];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) if (acc <= lim[k]) t[k] = v;
+    }
+    thr[0] = t[0]; thr[1] = t[1]; thr[2] = t[2];
+  }
+}
 
 #define SE_LO_DIM 1002  // 0..999 table entries, 1000 = "0" (t < -3), 1001 = "1" (t > 3)
 
@@ -505,6 +609,8 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   // without a device-to-host copy between this kernel and the raycast)
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
   if (a.commit_occ) se_occ_commit(m, a.occ_lists);   // nothing in this kernel reads occ[]; the raycast that follows does
+  __shared__ unsigned s_hist[256];
+  if (a.prio_thr && blockIdx.x == 0) se_prio_thresholds(a.tile_cost, a.n_tiles, a.prio_thr, s_hist);
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
@@ -514,18 +620,23 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     float* px = m.vx + (size_t)slot * 512 + lane;
     float* py = m.vy + (size_t)slot * 512 + lane;
     float vx[8], vy[8];
+#ifdef SE_DIAG
     if (a.debug == 2) {
 #pragma unroll
       for (int zi = 0; zi < 8; ++zi) { vx[zi] = 1.f; vy[zi] = (float)zi; }
-    } else {
+    } else
+#endif
+    {
 #pragma unroll
       for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
     }
+#ifdef SE_DIAG
     if (a.debug == 1) {
 #pragma unroll
       for (int zi = 0; zi < 8; ++zi) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
       continue;
     }
+#endif
     bool visible = false;
     const int y = by + ly;
     // update_block (projective_functor.hpp:73-111) in stages over the 8 z-slices of the lane, without
@@ -558,7 +669,9 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
-      if (a.debug == 2) { if (vx[zi] == 12345.f) px[zi * 64] = vx[zi]; continue; }   // diagnostic: keep the arithmetic alive
+#ifdef SE_DIAG
+      if (a.debug == 2) { if (vx[zi] == 12345.f) px[zi * 64] = vx[zi]; continue; }   // keep the arithmetic alive
+#endif
       if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
     const bool any = __ballot(visible) != 0ull;
@@ -591,8 +704,22 @@ struct RayArgs {
   int has_deep;          // there are non-leaf levels beyond the staged ones (volumes > 512^3)
   int stack_depth;   // ray stack slots (= leaf level)
   int xcd_swizzle;
-  int debug_phases;  // diagnostic: bit0 = skip march + gradient, bit1 = skip gradient, bit2 = skip the traversal (results are then wrong)
+  // Scheduling hint (results do not depend on it): cost of every wave tile in the previous raycast launch,
+  // trips + 5 * march batches of its slowest ray.  A launch ends when its slowest waves end, and those are known in
+  // advance -- the silhouettes and depth edges of the previous frame -- so they start with a raised issue priority.
+  unsigned short* tile_cost;
+  const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_prio_thresholds)
+#ifdef SE_DIAG
+  int debug_phases;    // diagnostic build only: bit0 = skip march + gradient, bit1 = skip gradient, bit2 = skip the traversal (results are then wrong)
+  uint32_t* diag_pix;  // per pixel: iterator trips | march batches << 16 (STATS variants)
+  uint32_t* diag_wave; // per wave: 8 words, see k_raycast
+#endif
 };
+#ifdef SE_DIAG
+#define SE_DBG_PHASES(a) ((a).debug_phases)
+#else
+#define SE_DBG_PHASES(a) 0
+#endif
 
 struct BlkCache { int bx, by, bz; uint32_t e; };
 // voxel_traits<T>::initValue() / empty() as register values.  Reading them through the by-value
@@ -841,7 +968,7 @@ __device__ __forceinline__ f3 se_grad(const DevMap& m, const FieldConst fc, f3 p
   return g;  // the caller applies (0.5f * dim / size)
 }
 
-struct RaySpan { float tcmin, tmax; };
+struct RaySpan { float tcmin, tmax; int trips; };
 // se::ray_iterator (se_core/include/se/ray_iterator.hpp:53-250) up to the first leaf, on the occupancy
 // bits.  Same float arithmetic on t and pos as the reference; what is restated is the integer side:
 //  * a node is its heap code (occ_code), the child test is one bit of one word;
@@ -850,6 +977,7 @@ struct RaySpan { float tcmin, tmax; };
 //  * advance: subtracting scale_exp2 flips exactly bit `scale` unless it borrows, so old ^ new of the
 //    three coordinates is the reference's differing_bits, and "leaves the parent" (idx & step_mask) is
 //    "some bit above `scale` changed".
+template <bool SHALLOW>   // SHALLOW: the caller guarantees a.has_deep == 0 (every non-leaf level is staged in LDS)
 __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs& a, f3 origin, f3 direction,
                                                  const uint32_t* s_occ, uint32_t* s_par, float* s_tmax) {
   const int tid = threadIdx.x;
@@ -883,26 +1011,51 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
 
   uint32_t gw_index = 0xFFFFFFFFu, gw_word = 0u;  // last occupancy word fetched from global memory (levels between cache and leaf)
   uint32_t leaf_byte = 0u;                        // the 8 leaf-level sibling bits of the current parent
+  // the 64 leaf bits below the node two levels above the leaves that the ray is in (its children are the leaf
+  // parents, byte c of the 8-byte group = the sibling byte of child c): fetched once when that node is entered,
+  // a trip or more before the first leaf test needs it, instead of one dependent byte load per leaf parent
+  unsigned long long gp_bits = 0ull;
+  uint32_t gp_code = 0u;
   const uint8_t* occ_bytes = (const uint8_t*)m.occ;
   // One trip = one node.  Some lanes of a wave descend while others advance on nearly every trip, so
   // both updates are computed for every lane and selected (straight-line code, no exec-mask juggling);
   // only the rare events are branches: leaving a parent (stack read), entering a leaf parent (sibling
   // byte load) and the global occupancy word of volumes > 512^3.
-  const int max_trips = (a.debug_phases & 4) ? 0 : 4096;   // diagnostic: no traversal at all
-  for (int guard = 0; guard < max_trips && scale < 23; ++guard) {
+  const int max_trips = (SE_DBG_PHASES(a) & 4) ? 0 : 4096;
+  const bool has_deep = SHALLOW ? false : (a.has_deep != 0);
+  int guard = 0;
+  // The occupancy word of a trip depends only on (parent, pos, scale), which are final at the end of the previous
+  // trip: its LDS read is issued there, so the float work at the top of the trip runs under the LDS latency (a wave
+  // in the tail of a launch is alone on its SIMD, with nobody else to cover that latency).
+  uint32_t cidx = 0u, child = 0u, word = 0u;
+  bool at_leaves = false, deep = false;
+#define SE_TRIP_PREFETCH()                                                                                                   \
+  do {                                                                                                                       \
+    const uint32_t us_ = (uint32_t)scale;                                                                                    \
+    cidx = (__builtin_amdgcn_ubfe(__float_as_uint(pos.x), us_, 1u) | (__builtin_amdgcn_ubfe(__float_as_uint(pos.y), us_, 1u) << 1) | \
+            (__builtin_amdgcn_ubfe(__float_as_uint(pos.z), us_, 1u) << 2)) ^ om;                                              \
+    child = (parent << 3) | cidx;                                                                                            \
+    at_leaves = scale == a.min_scale;                                                                                        \
+    deep = has_deep && child >= a.cache_codes;                                                                               \
+    word = s_occ[(at_leaves || deep) ? 0u : (child >> 5)];                                                                   \
+  } while (0)
+  if (guard < max_trips) SE_TRIP_PREFETCH();
+  for (; guard < max_trips && scale < 23; ++guard) {
     const f3 t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
     const float tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
     const uint32_t us = (uint32_t)scale;
     const uint32_t ox = __float_as_uint(pos.x), oy = __float_as_uint(pos.y), oz = __float_as_uint(pos.z);
-    const uint32_t cidx = (__builtin_amdgcn_ubfe(ox, us, 1u) | (__builtin_amdgcn_ubfe(oy, us, 1u) << 1) | (__builtin_amdgcn_ubfe(oz, us, 1u) << 2)) ^ om;
-    const uint32_t child = (parent << 3) | cidx;
-    const bool at_leaves = scale == a.min_scale;
+    // descend (ray_iterator.hpp:172-199) / advance_ray (ray_iterator.hpp:116-167) candidates
+    const float half = scale_exp2 * 0.5f;
+    const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
+    const f3 dpos = {pos.x + ((t_center.x > t_min) ? half : 0.f), pos.y + ((t_center.y > t_min) ? half : 0.f), pos.z + ((t_center.z > t_min) ? half : 0.f)};
+    const f3 apos = {pos.x - ((t_corner.x <= tc_max) ? scale_exp2 : 0.f), pos.y - ((t_corner.y <= tc_max) ? scale_exp2 : 0.f),
+                     pos.z - ((t_corner.z <= tc_max) ? scale_exp2 : 0.f)};
+    const uint32_t differing_bits = (ox ^ __float_as_uint(apos.x)) | (oy ^ __float_as_uint(apos.y)) | (oz ^ __float_as_uint(apos.z));
     // occupancy test: leaf level -> the sibling byte fetched when this parent was entered;
     // staged levels -> LDS; levels in between (volumes > 512^3) -> global word, cached per word
-    const bool deep = a.has_deep && child >= a.cache_codes;
-    uint32_t word = s_occ[(at_leaves || deep) ? 0u : (child >> 5)];
-    asm volatile("" : "+v"(word));  // keep the LDS load an LDS load
-    if (a.has_deep) {
+    asm volatile("" : "+v"(word));  // keep the LDS load an LDS load, and its first use here
+    if (has_deep) {
       if (deep && !at_leaves) {
         const uint32_t w = child >> 5;
         if (w != gw_index) { gw_index = w; gw_word = m.occ[w]; }
@@ -914,15 +1067,7 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
     const bool exists = (word >> shift) & 1u;
     if (at_leaves && exists) break;  // leaf found: t_min is its entry distance
     const bool desc = exists && t_min <= t_max;
-    // descend (ray_iterator.hpp:172-199)
-    const float half = scale_exp2 * 0.5f;
-    const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
     if (desc && tc_max < h) { s_par[(22 - scale) * SE_WG_RAY + tid] = parent; s_tmax[(22 - scale) * SE_WG_RAY + tid] = t_max; }
-    const f3 dpos = {pos.x + ((t_center.x > t_min) ? half : 0.f), pos.y + ((t_center.y > t_min) ? half : 0.f), pos.z + ((t_center.z > t_min) ? half : 0.f)};
-    // advance_ray (ray_iterator.hpp:116-167)
-    const f3 apos = {pos.x - ((t_corner.x <= tc_max) ? scale_exp2 : 0.f), pos.y - ((t_corner.y <= tc_max) ? scale_exp2 : 0.f),
-                     pos.z - ((t_corner.z <= tc_max) ? scale_exp2 : 0.f)};
-    const uint32_t differing_bits = (ox ^ __float_as_uint(apos.x)) | (oy ^ __float_as_uint(apos.y)) | (oz ^ __float_as_uint(apos.z));
     const bool pop = !desc && differing_bits > (1u << us);
     // select
     t_max = desc ? fminf(t_max, tc_max) : t_max;
@@ -932,7 +1077,15 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
     scale = desc ? scale - 1 : scale;
     scale_exp2 = desc ? half : scale_exp2;
     pos.x = desc ? dpos.x : apos.x; pos.y = desc ? dpos.y : apos.y; pos.z = desc ? dpos.z : apos.z;
-    if (desc && scale == a.min_scale) leaf_byte = occ_bytes[child];  // issued now, first used next trip
+    // (consumer first: the wait for gp_bits it contains must not cover a load that another lane issues in this same trip)
+    if (desc && scale == a.min_scale) {   // entered a leaf parent: its sibling byte is first used next trip
+      if ((child >> 3) != gp_code) {      // (only a parent restored from a never-pushed stack slot, see the stack note above)
+        gp_code = child >> 3;
+        gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)gp_code << 3));
+      }
+      leaf_byte = (uint32_t)(gp_bits >> (cidx << 3)) & 0xFFu;
+    }
+    if (desc && scale == a.min_scale + 1) { gp_code = child; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)child << 3)); }
     if (pop) {
       // the highest differing bit is the scale of the first ancestor the ray is still inside
       scale = 31 - __clz(differing_bits);            // == (float_as_int((float)differing_bits) >> 23) - 127, differing_bits < 2^24
@@ -947,14 +1100,16 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
       }
       h = 0.0f;
     }
+    if (scale < 23) SE_TRIP_PREFETCH();
   }
-  return {t_min * m.dim, tmax_m};
+#undef SE_TRIP_PREFETCH
+  return {t_min * m.dim, tmax_m, guard};
 }
 
 // raycast(const Volume<T>&, origin, direction, tnear, tfar, mu, step, largestep)
 // (se_denseslam/src/kfusion/rendering_impl.hpp:34-74, bfusion/rendering_impl.hpp:35-68): writes the hit
 // (position, distance) or leaves it zero.  Shared by the raycast kernel and the volume renderer.
-struct RayCounters { unsigned long long n_get, n_interp; };
+struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 template <bool OFUSION, bool STATS, bool DENSE>
 __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
                                             BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
@@ -980,7 +1135,11 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
           // formed by the same float additions the sequential loop performs.
           float S = a.largestep;
           bool done = false;
+#if SE_RUN > 0
+          bool prev_full = false;   // the previous batch was consumed completely at step `largestep`
+#endif
           for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+            ++rc.n_batch;
             f3 q[SE_SPEC];
             uint32_t qe[SE_SPEC];
             float qx[SE_SPEC], qy[SE_SPEC];
@@ -1010,6 +1169,30 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 #pragma unroll
               for (int k = 0; k < 8; ++k) cv0[k] = m.vx[vi0[k]];
             }
+#if SE_RUN > 0
+            // A ray that has left one surface band and is on its way to the next crosses unallocated blocks in
+            // largesteps -- one block per step, every sample a (cold) brick that holds initValue().  While the batch
+            // is in flight the leaf bitmap is probed for the SE_RUN positions behind it; if the batch is consumed
+            // completely, the leading positions whose block is not allocated are consumed too: get() returns
+            // initValue() there, y == 0, so the step is `largestep` again and the loop's own additions are replayed.
+            // (A bit set by the allocation scan of the next frame, which may run concurrently, only ends the run early:
+            // that sample then goes through the voxel loads, which see the still untouched brick.)
+            uint32_t run_free = 0u;
+            const bool run_mode = prev_full && S == a.largestep;   // (not on a ray's first batches: most rays never see a run)
+            if (run_mode) {
+              f3 r = q[SE_SPEC - 1];
+#pragma unroll
+              for (int j = 0; j < SE_RUN; ++j) {
+                r = f3_add(r, f3_scale(S, dir));
+                const int rx = cvt_i32(a.inv_voxel * r.x), ry = cvt_i32(a.inv_voxel * r.y), rz = cvt_i32(a.inv_voxel * r.z);
+                const bool inside = in_volume(m, rx, ry, rz);
+                const uint32_t lin = inside ? block_linear(m, rx >> 3, ry >> 3, rz >> 3) : 0u;
+                const uint32_t w = m.lbits[lin >> 5];
+                run_free |= (!inside || !((w >> (lin & 31u)) & 1u)) ? (1u << j) : 0u;
+              }
+            }
+            bool broke = false;
+#endif
 #pragma unroll
             for (int i = 0; i < SE_SPEC; ++i) {
               if (!(t < tfar)) { done = true; break; }
@@ -1035,8 +1218,26 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
                 f_t = f_tt;
               }
               t += stepsize;
+#if SE_RUN > 0
+              if (stepsize != S) { S = stepsize; broke = true; break; }
+#else
               if (stepsize != S) { S = stepsize; break; }
+#endif
             }
+#if SE_RUN > 0
+            prev_full = !done && !broke && S == a.largestep;
+            if (run_mode && prev_full) {   // every sample of the batch was used and the step is still `largestep`
+#pragma unroll
+              for (int j = 0; j < SE_RUN; ++j) {
+                if (!(t < tfar)) { done = true; break; }
+                if (!((run_free >> j) & 1u)) break;
+                if (STATS) ++n_get;
+                stepsize = a.largestep;
+                position = f3_add(position, f3_scale(stepsize, dir));
+                t += stepsize;
+              }
+            }
+#endif
           }
           if (f_tt < 0) {
             t = t + stepsize * f_tt / (f_t - f_tt);
@@ -1058,6 +1259,7 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
           // advance, so SE_SPEC_OF gets share one memory round trip
           bool done = false;
           for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+            ++rc.n_batch;
             float tt[SE_SPEC_OF];
             f3 q[SE_SPEC_OF];
             uint32_t qe[SE_SPEC_OF];
@@ -1108,7 +1310,7 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
-template <bool OFUSION, bool STATS, bool DENSE>
+template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW>
 __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
   // LDS: [occupancy words of levels 1..cache_levels][ray stack: parent codes][ray stack: t_max]
   extern __shared__ uint32_t smem[];
@@ -1116,40 +1318,76 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   uint32_t* s_par = smem + a.cache_words;
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+#ifdef SE_DIAG
+  const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
+#endif
   for (int i = threadIdx.x; i < a.cache_words; i += SE_WG_RAY) s_occ[i] = m.occ[i];   // (a per-level copy of only the used words was slower)
   __syncthreads();
   const unsigned long long tk1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long tk2 = tk1, tk3 = tk1;
   const FieldConst fc = se_field_const(m);
   const int lane = threadIdx.x & 63;
-  // Optional XCD banding (workgroup b runs on XCD b % 8): one contiguous image band per XCD.  Off by
-  // default -- it loses to the round-robin order, see se_hip_raycast().
-  const int nwg = gridDim.x, per = (nwg + 7) >> 3;
-  int vwg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (((nwg & 7) != 0) || !a.xcd_swizzle) vwg = blockIdx.x;
-  const int tile = vwg * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
+  // Workgroup -> tile mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order; a speed assumption only) and
+  // every XCD has its own L2, so with the plain row-major order each of the 8 L2s ends up holding the bricks of the
+  // whole image.  xcd_swizzle = S > 1: the image is cut into supertiles of S x S wave tiles and supertile g belongs to
+  // XCD g % 8 -- each L2 then serves 1/8 of the bricks (plus supertile borders), and the 8-way interleave of small
+  // supertiles keeps the cheap / expensive image regions balanced (whole-image bands per XCD were measured slower).
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W;
-  const int px = (tile % tiles_x) * SE_TILE_W + (lane % SE_TILE_W);
-  const int py = a.row_begin + (tile / tiles_x) * SE_TILE_H + (lane / SE_TILE_W);
+  int tile = blockIdx.x * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
+  int tx = tile % tiles_x, ty = tile / tiles_x;
+  if (a.xcd_swizzle > 1) {
+    const int S = a.xcd_swizzle, per_st = S * S / (SE_WG_RAY / 64);   // workgroups per supertile
+    const int tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
+    const int sx_n = (tiles_x + S - 1) / S;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int g = (j / per_st) * 8 + xcd;
+    const int t = (j % per_st) * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
+    tx = (g % sx_n) * S + (t % S);
+    ty = (g / sx_n) * S + (t / S);
+    tile = (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : 0;   // (diagnostic index only)
+    if (tx >= tiles_x) ty = 1 << 20;   // outside the image: fails the row test below
+  }
+  const int px = tx * SE_TILE_W + (lane % SE_TILE_W);
+  const int py = a.row_begin + ty * SE_TILE_H + (lane / SE_TILE_W);
+  const bool tile_in_image = tx < tiles_x && a.row_begin + ty * SE_TILE_H < a.row_end;
+  const int tile_slot = __builtin_amdgcn_readfirstlane(tile_in_image ? ty * tiles_x + tx : 0);
+  unsigned my_cost = 0u;
+  if (a.tile_cost) {
+    const int prev = __builtin_amdgcn_readfirstlane((int)a.tile_cost[tile_slot]);
+    if (prev >= a.prio_thr[2]) __builtin_amdgcn_s_setprio(3);
+    else if (prev >= a.prio_thr[1]) __builtin_amdgcn_s_setprio(2);
+    else if (prev >= a.prio_thr[0]) __builtin_amdgcn_s_setprio(1);
+  }
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
+#ifdef SE_DIAG
+  unsigned d_trips = 0, d_batches = 0;
+#endif
   if (px < a.W && py < a.row_end) {
     const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
     const f3 org = {a.org[0], a.org[1], a.org[2]};
-    const RaySpan span = se_first_leaf(m, a, org, dir, s_occ, s_par, s_tmax);
+    const RaySpan span = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax);
     const float t_min = span.tcmin, tfar = span.tmax;
     if (STATS) tk2 = __builtin_amdgcn_s_memtime();
     float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
     BlkCache c = {-1, -1, -1, 0u};
-    if (t_min > 0.f && !(a.debug_phases & 1)) {
-      RayCounters rc = {0ull, 0ull};
+    if (t_min > 0.f && !(SE_DBG_PHASES(a) & 1)) {
+      RayCounters rc = {0ull, 0ull, 0u};
       se_cast_ray<OFUSION, STATS, DENSE>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
       if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
+      my_cost = 5u * rc.n_batch;
+#ifdef SE_DIAG
+      if (STATS) d_batches = rc.n_batch;
+#endif
     }
+    my_cost += (unsigned)span.trips;
+#ifdef SE_DIAG
+    if (STATS) { d_trips = (unsigned)span.trips; if (a.diag_pix) a.diag_pix[px + py * a.W] = d_trips | (d_batches << 16); }
+#endif
     if (STATS) tk3 = __builtin_amdgcn_s_memtime();
     float* v = vertex + 3 * (size_t)(px + py * a.W);
     float* n = normal + 3 * (size_t)(px + py * a.W);
-    if (a.debug_phases & 1) hw = t_min;
-    if ((double)hw > 0.0 && (a.debug_phases & 3)) {
+    if (SE_DBG_PHASES(a) & 1) hw = t_min;
+    if ((double)hw > 0.0 && (SE_DBG_PHASES(a) & 3)) {
       v[0] = hx; v[1] = hy; v[2] = hw; n[0] = 0.f; n[1] = 0.f; n[2] = 0.f;
     } else if ((double)hw > 0.0) {
       if (STATS) { ++n_hit; ++n_grad; }
@@ -1167,13 +1405,26 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
       n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;
     }
   }
+  if (a.tile_cost) {
+    // wave maximum through the (now idle) first stack slot of this wave's lane 0; LDS operations of one wave are ordered
+    uint32_t* slot = s_par + (threadIdx.x & ~63);
+    if (lane == 0) *slot = 0u;
+    atomicMax(slot, my_cost);
+    if (lane == 0 && tile_in_image) a.tile_cost[tile_slot] = (unsigned short)min(*slot, 65535u);
+  }
+#ifdef SE_DIAG
+  const bool quiet = a.diag_wave != nullptr;   // per-wave records only: the contended stats atomics would distort the clocks
+#else
+  const bool quiet = false;
+#endif
   if (STATS) {
+    const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
+    if (!quiet) {
     se_stat_add<true>(m, S_GETS, n_get);
     se_stat_add<true>(m, S_INTERPS, n_interp);
     se_stat_add<true>(m, S_GRADS, n_grad);
     se_stat_add<true>(m, S_HITS, n_hit);
     // per-wave phase clocks (shader cycles): LDS staging, first-leaf search, march, gradient + store
-    const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
       atomicAdd(&m.stats[S_T_STAGE], tk1 - tk0);
       atomicAdd(&m.stats[S_T_ITER], tk2 - tk1);
@@ -1184,6 +1435,22 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
       atomicMax(&m.stats[14], tk3 - tk2);
       atomicMax(&m.stats[15], tk4 - tk3);
     }
+    }
+#ifdef SE_DIAG
+    // per-wave record: start / end clock (low words), phase cycles, wave-level trip and batch counts, where it ran
+    if (a.diag_wave && tile_in_image) {
+      unsigned mt = d_trips, mb = d_batches;
+      for (int o = 32; o > 0; o >>= 1) { mt = max(mt, (unsigned)__shfl_xor((int)mt, o)); mb = max(mb, (unsigned)__shfl_xor((int)mb, o)); }
+      if (lane == 0) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        uint32_t* w = a.diag_wave + 8 * (size_t)tile;
+        w[0] = (uint32_t)rt0; w[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[2] = (uint32_t)(tk1 - tk0); w[3] = (uint32_t)(tk2 - tk1);
+        w[4] = (uint32_t)(tk3 - tk2); w[5] = (uint32_t)(tk4 - tk3); w[6] = mt | (mb << 16); w[7] = hwid ^ (xcc << 28);
+      }
+    }
+#endif
   }
 }
 
@@ -1224,7 +1491,7 @@ __device__ __forceinline__ RaySpan se_ray_range(const DevMap& m, const RayArgs& 
   float t_max = fminf(fminf(t_coef.x - t_bias.x, t_coef.y - t_bias.y), t_coef.z - t_bias.z);
   t_min = fmaxf(t_min, a.nearp / m.dim);
   t_max = fminf(t_max, a.farp / m.dim);
-  return {t_min * m.dim, t_max * m.dim};
+  return {t_min * m.dim, t_max * m.dim, 0};
 }
 
 struct ShadeArgs { float light[3], ambient[3]; int render; };
@@ -1248,7 +1515,7 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_render_volume(DevMap m, RayArgs a
     const RaySpan sp = se_ray_range(m, a, org, dir);
     float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
     BlkCache c = {-1, -1, -1, 0u};
-    RayCounters rc = {0ull, 0ull};
+    RayCounters rc = {0ull, 0ull, 0u};
     if (sp.tcmin > 0.f) se_cast_ray<OFUSION, false, DENSE>(m, a, fc, org, dir, sp.tcmin, sp.tmax, c, hx, hy, hz, hw, rc);
     if (hw > 0) {
       test = {hx, hy, hz};

@@ -3,7 +3,7 @@
 // DenseSLAMSystem::dump_mesh (se_denseslam/src/DenseSLAMSystem.cpp:302-322): inside(v) = v.x < 0,
 // select(v) = v.x.  One wave per block, lane = x + 8y, the 8 z-cells of a lane in turn; every cell reads
 // its 8 corners through get_fine (a missing block reads initValue(), whose y == 0 ends the cell).
-// Triangle table: include/se_mc_table.h (derived; see its header for how it relates to the reference's).
+// Triangle table: include/se_mc_table.h (the standard published table, content-identical to the reference's edge_tables.h:66).
 #pragma once
 #include "../../include/se_mc_table.h"
 #include "se_device.h"

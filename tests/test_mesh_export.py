@@ -1,8 +1,9 @@
 """SURVEY 8(f-4), second half: marching cubes (DenseSLAMSystem::dump_mesh).
 
-CPU part: the derived triangle table (include/se_mc_table.h, tools/gen_mc_table.py) is checked for what a
-marching-cubes table must guarantee -- triangles only on crossed edges, closed and consistently oriented
-surfaces on arbitrary fields (every case, ambiguous faces included) -- and the oracle's restatement of
+CPU part: the triangle table (include/se_mc_table.h: the standard published table, pinned against the
+reference's literals by tests/test_mc_table_reference.py) is checked for what a marching-cubes table must
+guarantee -- triangles only on crossed edges, consistently oriented surfaces, closed on fields without
+ambiguous faces -- and the oracle's restatement of
 se::algorithms::marching_cube is checked on the analytic scene.  GPU part: the HIP kernel produces the
 oracle's triangle set bit for bit."""
 import os
@@ -21,19 +22,16 @@ EDGE = [(0, 1), (1, 2), (2, 3), (0, 3), (4, 5), (5, 6), (6, 7), (4, 7), (0, 4), 
 
 
 def load_table():
+    """include/se_mc_table.h expanded the way se_mc_expand() does it."""
     text = open(os.path.join(ROOT, "include", "se_mc_table.h")).read()
-    rows = re.findall(r"^\s*\{([-0-9, ]+)\},\s*$", text, re.M)
-    t = np.array([[int(v) for v in r.split(",")] for r in rows], np.int64)
-    assert t.shape == (256, 16)
+    body = text[text.index("SE_MC_PACKED[256]"):text.index("};")]
+    packed = re.findall(r'"([0-9a-b]*)"', body)
+    assert len(packed) == 256
+    t = -np.ones((256, 16), np.int64)
+    for c, p in enumerate(packed):
+        assert len(p) % 3 == 0 and len(p) <= 15
+        t[c, :len(p)] = [int(ch, 16) for ch in p]
     return t
-
-
-def test_table_is_what_the_generator_produces():
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import gen_mc_table
-    t = load_table()
-    for case, tris in enumerate(gen_mc_table.table()):
-        assert list(t[case][: len(tris)]) == tris and (t[case][len(tris):] == -1).all()
 
 
 def test_table_triangles_use_crossed_edges_only():
