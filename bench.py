@@ -54,8 +54,12 @@ def parse():
     ap.add_argument("--event-stride", type=int, default=10,
                     help="record per-kernel HIP events on every n-th timed frame (1 = every frame; events cost host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=30, help="timed frames of the CPU baseline sample")
-    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU baseline sample (median is reported)")
+    ap.add_argument("--cpu-frames", type=int, default=20, help="timed frames of the CPU baseline sample")
+    ap.add_argument("--cpu-reps", type=int, default=4, help="repetitions of the CPU baseline sample (the fastest is reported, all are listed)")
+    ap.add_argument("--sustain", type=int, default=200, help="N = 1: after the K contract steps keep going until this many frames have been timed in total (0 = off)")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU clock ramp-up before the warm-up frames (see prewarm())")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra N = 1 legs (closed loop, tracking on, pooled bricks)")
+    ap.add_argument("--mode-frames", type=int, default=60, help="timed frames of each extra leg")
     ap.add_argument("--detail", type=str, default="", help="write a detailed JSON report to this path")
     return ap.parse_args()
 
@@ -121,30 +125,39 @@ def cpu_baseline(args, n_timed: int):
     except Exception:
         native = False
     field = binding.SDF if args.field == "sdf" else binding.OFUSION
-    reps = []
-    for _ in range(max(1, args.cpu_reps)):
-        o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
-        model, physical, logical = host_cpu()
-        # OMP_NUM_THREADS = physical cores, capped by what the OpenMP runtime may use in this container
-        # (not sched_getaffinity: OMP_PROC_BIND has already pinned the calling thread to one core by now)
-        o.lib.so_set_num_threads(max(1, min(physical, o.lib.so_num_threads())))
-        threads = o.lib.so_num_threads()
-        s, _ = make_stream(args, 4 + n_timed)
-        t_int_sum, t_ray_sum = 0.0, 0.0
-        for f in range(4 + n_timed):
-            d, pose = s.depth(f), s.pose(f)
-            t0 = time.perf_counter()
-            o.integrate(d, pose, s.k, args.mu, f)
-            t1 = time.perf_counter()
-            o.raycast(pose, s.k, args.mu, f)
-            t2 = time.perf_counter()
-            if f >= 4:
-                t_int_sum += t1 - t0
-                t_ray_sum += t2 - t1
-        o.close()
-        reps.append((n_timed / (t_int_sum + t_ray_sum), t_int_sum, t_ray_sum))
-    reps.sort()
-    fps, t_int_sum, t_ray_sum = reps[len(reps) // 2]          # median repetition
+    model, physical, logical = host_cpu()
+    probe = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
+    avail = probe.lib.so_num_threads()          # what the OpenMP runtime may use in this container
+    probe.close()
+    # The box is shared and has two sockets: 128 threads over both are not always faster than 64 on one, and single
+    # repetitions vary by several x with the other tenants' load.  Every repetition of every thread count is listed;
+    # the figure reported is the FASTEST repetition (min time), i.e. the CPU path at its best on this host.
+    cands = sorted({max(1, min(physical, avail)), max(1, min(physical // 2, avail))}, reverse=True)
+    by_threads = {}
+    for nthr in cands:
+        reps = []
+        for _ in range(max(1, args.cpu_reps)):
+            o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
+            o.lib.so_set_num_threads(nthr)
+            s, _ = make_stream(args, 4 + n_timed)
+            t_int_sum, t_ray_sum = 0.0, 0.0
+            for f in range(4 + n_timed):
+                d, pose = s.depth(f), s.pose(f)
+                t0 = time.perf_counter()
+                o.integrate(d, pose, s.k, args.mu, f)
+                t1 = time.perf_counter()
+                o.raycast(pose, s.k, args.mu, f)
+                t2 = time.perf_counter()
+                if f >= 4:
+                    t_int_sum += t1 - t0
+                    t_ray_sum += t2 - t1
+            o.close()
+            reps.append((n_timed / (t_int_sum + t_ray_sum), t_int_sum, t_ray_sum))
+        reps.sort()
+        by_threads[nthr] = reps
+    threads = max(by_threads, key=lambda t: by_threads[t][-1][0])
+    reps = by_threads[threads]
+    fps, t_int_sum, t_ray_sum = reps[-1]          # fastest repetition (min time)
     # one thread, a shorter sample of the same frames (SURVEY 8d asks for the 1-thread figure beside it)
     n1 = max(2, min(n_timed, 6))
     o = binding.OraclePipeline(field, args.res, args.dim, args.width, args.height, native=native)
@@ -159,16 +172,91 @@ def cpu_baseline(args, n_timed: int):
         if f >= 4:
             t1 += time.perf_counter() - t0
     o.close()
-    o.lib.so_set_num_threads(threads)
     single = n1 / t1
     return {"value": fps, "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"frames 4..{3 + n_timed} of the same stream after 4 executed warm-up frames "
-                      f"({n_timed} timed frames, median of {len(reps)} repetitions, OpenMP {threads} threads, "
+                      f"({n_timed} timed frames, fastest of {len(reps)} repetitions, OpenMP {threads} threads, "
                       f"{'-march=native' if native else '-march=x86-64-v3'} build)",
             "cpu": f"{model}, {physical} physical cores / {logical} logical CPUs",
             "ms_integration": 1e3 * t_int_sum / n_timed, "ms_raycasting": 1e3 * t_ray_sum / n_timed,
-            "all_repetitions_fps": [r[0] for r in reps],
+            "all_repetitions_fps": {str(t): [r[0] for r in v] for t, v in by_threads.items()}, "median_fps": reps[len(reps) // 2][0],
+            "spread": reps[-1][0] / reps[0][0],
             "single_thread": {"value": single, "unit": "frames/s", "sample": f"frames 4..{3 + n1}, 1 OpenMP thread"}}
+
+
+def prewarm(args, field, depth_ptrs, poses, k, device, ms: float = 90.0):
+    """Untimed: keeps the GPU busy with the same kernels on a scratch map for `ms` milliseconds right before a timed
+    region.  An MI355X that has been idle sits in a low-power state; measured on the bench box (tools/long_run.py), the first
+    ~20 ms of sustained load end in ONE stall of 35-40 ms while the clocks come up (frames run 78-81 us before it and
+    75-76 us ever after, 3000 frames checked).  A 1.6 ms timed region either dodges it or, 200 frames long, eats it whole;
+    with the ramp behind us the K timed steps measure the steady state."""
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    p = DenseSLAMPipeline((args.width, args.height), args.res, args.dim, field_type=field, device=device)
+    n = min(len(depth_ptrs), 24)
+    t0 = time.perf_counter()
+    f = 0
+    while time.perf_counter() - t0 < ms * 1e-3:
+        for _ in range(16):
+            i = f % n if (f // n) % 2 == 0 else n - 1 - f % n      # ping-pong over the first frames
+            p.set_depth_device(depth_ptrs[i]); p.setPose(poses[i])
+            p.integration(k, 1, args.mu, f); p.raycasting(k, args.mu, f)
+            f += 1
+        p.sync()
+    p.close()
+    return f
+
+
+def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
+    """N = 1 legs beside the headline (same frames, same library, fresh map each), frames/s:
+      closed_loop  integration() + raycasting() + se_hip_sync() per frame -- the reference's own bracketing
+                   (se_apps/src/benchmark.cpp:148-167): nothing of frame f+1 is issued before frame f has finished,
+                   i.e. what a SLAM loop whose next pose depends on this raycast can use;
+      tracking_on  the full loop tracking() -> integration() -> raycasting() with the ICP-tracked pose (GT pose for
+                   frames 0..3 only); tracking synchronises with the host once per ICP iteration;
+      pooled       the headline's pipelined loop on pooled bricks (max_blocks set: bump-allocated bricks behind the
+                   index instead of one brick slot per grid cell)."""
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    W, H, N, dim, mu = args.width, args.height, args.res, args.dim, args.mu
+    out = {}
+
+    def run(label, per_frame_sync, track, **kw):
+        prewarm(args, field, depth_ptrs, poses, k, device)
+        p = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=device, **kw)
+        tracked = 0
+        t0 = None
+        for f in range(warm + n):
+            if f == warm:
+                p.sync()
+                t0 = time.perf_counter()
+            p.set_depth_device(depth_ptrs[f])
+            if track and f > 3:
+                tracked += int(p.tracking(k, 1e-5, 1, f))
+            else:
+                p.setPose(poses[f])
+            p.integration(k, 1, mu, f)
+            p.raycasting(k, mu, f)
+            if per_frame_sync:
+                p.sync()
+        p.sync()
+        dt = time.perf_counter() - t0
+        rec = {"fps": n / dt, "ms_per_frame": 1e3 * dt / n, "frames": n}
+        if track:
+            err = np.abs(p.getPose()[:3, 3] - np.asarray(poses[warm + n - 1])[:3, 3]).max()
+            rec.update(tracked_frames=tracked, of=warm + n - 4, final_position_error_m=float(err),
+                       note="ICP-tracked poses (GT for frames 0..3 only).  On this analytic room the reference's point-to-plane ICP "
+                            "under-tracks the 1 mm / frame translation -- the CPU oracle drifts identically (tests/test_gpu_tracking.py "
+                            "pins GPU == oracle); the leg measures the loop's speed, not the tracker's accuracy")
+        p.counts()   # raises on pool / key-list overflow
+        p.close()
+        out[label] = rec
+
+    run("closed_loop", True, False)
+    run("tracking_on", True, True)
+    nb = {512: 1 << 16, 1024: 1 << 19}.get(N, 1 << 21)
+    run("pooled", False, False, max_blocks=nb)
+    out["closed_loop"]["note"] = "per-frame se_hip_sync(); scan / sweep / raycast of a frame strictly in sequence"
+    out["pooled"]["note"] = f"max_blocks = {nb}"
+    return out
 
 
 def pmc_traffic(kernel: str, args):
@@ -222,7 +310,10 @@ def main():
     W, H, N, dim, mu = args.width, args.height, args.res, args.dim, args.mu
     warm = max(args.warmup, 4)   # frames 0..3 are the reference's own warm-up (forced integration, no raycast before frame 3)
     K = args.steps
-    F = warm + K
+    # N = 1: the K contract steps are followed, in a second timed region, by as many frames as it takes to have
+    # `--sustain` frames timed in total (K = 20 is 1.6 ms of GPU time: too short to be a stable figure on its own)
+    extra = max(0, args.sustain - K) if (world == 1 and args.sustain > 0) else 0
+    F = warm + K + extra
 
     # ---- inputs: the whole stream resident in HBM before anything is timed
     stream, stream_name = make_stream(args, F)
@@ -233,6 +324,7 @@ def main():
     depth = torch.from_numpy(host_depth).to(dev)
     depth_ptrs = [depth[f].data_ptr() for f in range(F)]
 
+    prewarm_frames = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else 0
     sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank)
 
     def barrier():
@@ -247,10 +339,13 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for f in range(warm, F):
+    throttle = int(os.environ.get("SE_BENCH_THROTTLE", "0"))
+    for f in range(warm, warm + K):
         if not args.no_events:
             sp.p.enable_timing((f - warm) % stride == 0)   # sampled: HIP events on the launch stream
         sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+        if throttle and (f - warm) % throttle == throttle - 1:
+            sp.p.sync()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -259,6 +354,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    sustained = None
+    if extra:
+        t2 = time.perf_counter()
+        for f in range(warm + K, F):
+            if not args.no_events:
+                sp.p.enable_timing((f - warm) % stride == 0)
+            sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        sustained = {"frames": K + extra, "fps": (K + extra) / (elapsed + (t3 - t2)), "fps_second_region": extra / (t3 - t2),
+                     "note": f"the K = {K} contract steps plus {extra} more frames of the same stream, two timed regions added up"}
     timings = sp.p.timings(reset=True) if not args.no_events else None
     sp.p.enable_timing(False)
     nblocks, nnodes = sp.p.counts()
@@ -275,15 +381,22 @@ def main():
             "dtype": "f32", "data": "real (.raw)" if args.raw else "synthetic",
             "config": {"workload": f"{stream_name} {W}x{H} -> {N}^3 / {dim} m "
                                    f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
-                                   f"GT poses, frames {warm}..{F - 1} timed",
+                                   f"GT poses, frames {warm}..{warm + K - 1} timed",
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists",
-                       "blocks_allocated": nblocks, "nodes_allocated": nnodes},
+                       "blocks_allocated": nblocks, "nodes_allocated": nnodes,
+                       "prewarm": f"{prewarm_frames} untimed frames on a scratch map before the W warm-up frames (GPU clock ramp, see bench.py prewarm())"},
         }
+        if sustained:
+            result["sustained"] = sustained
 
     # ---- roofline of the dominant kernel (rank 0, its own share of the image)
-    if rank == 0 and timings is not None and world > 1:
-        result["kernels"] = {kk: {"avg_us": 1e3 * v["ms_sum"] / v["launches"], "launches": v["launches"]}
-                             for kk, v in timings.items() if v["launches"]}
+    if timings is not None and world > 1:
+        mine = {kk: {"avg_us": 1e3 * v["ms_sum"] / v["launches"], "launches": v["launches"]} for kk, v in timings.items() if v["launches"]}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            result["kernels"] = mine
+            result["per_rank_kernels"] = everyone    # rank r raycasts / scans rows row_partition(H, world)[r]; the sweep is replicated
     if rank == 0 and timings is not None and world == 1:
         rows = (0, H)
         rp = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=local_rank)
@@ -298,7 +411,8 @@ def main():
             rp.raycasting(k, mu, f)
         st = rp.stats()
         rp.close()
-        abytes = algorithmic_bytes(st, K, W, H, 8 if field == SDF else 16)
+        abytes = algorithmic_bytes(st, F - warm, W, H, 8 if field == SDF else 16)
+        device_voxel_bytes = 8   # what the HIP path stores per voxel for BOTH field types (x, y float planes); OFusion's reference layout is 16 B
         per_kernel = {}
         for kk, v in timings.items():
             if v["launches"] == 0:
@@ -321,8 +435,14 @@ def main():
             result["roofline"]["traffic"] = tr[0]
             result["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr[1]
         result["kernels"] = per_kernel
-        result["work_per_frame"] = {kk: st[kk] / K for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
+        result["work_per_frame"] = {kk: st[kk] / (F - warm) for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
+        if field != SDF:   # the reference-layout figure flatters OFusion: say what the device really moves
+            dbytes = algorithmic_bytes(st, F - warm, W, H, device_voxel_bytes)
+            result["roofline"]["device_layout_bytes_per_launch"] = dbytes[dom]
+            result["roofline"]["device_layout_frac"] = dbytes[dom] / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
 
+    if rank == 0 and world == 1 and not args.no_modes:
+        result["modes"] = extra_modes(args, field, depth_ptrs, poses, k, warm, min(args.mode_frames, F - warm), local_rank)
     del depth
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, args.cpu_frames)

@@ -12,8 +12,9 @@
  *   getModelDimensions()/getModelResolution()/getComputationResolution(), renderVolume()/renderTrack()/
  *   renderDepth(), dump_mesh(), setViewPose()/getViewPose(), synchroniseDevices().
  * What differs, because the map lives in HBM:
- *   getMap() returns a host snapshot (MapSnapshot: blocks sorted by Morton key) instead of a
- *   shared_ptr<se::Octree>; getVertex()/getNormal() download vertex_/normal_.
+ *   getMap(std::shared_ptr<se::Octree<FieldType>>&) materialises the device map as a host pointer octree with the reference's
+ *   node / block layout and read interface (include/se/octree.hpp) -- a snapshot, not the live map; getMap(MapSnapshot&) is
+ *   the flat form (blocks sorted by Morton key); getVertexNormal() downloads vertex_/normal_.
  *   tracking() runs the reference's ICP on the device; poses can still be injected
  *   with setPose(), as the reference's GUI does with ground truth (se_apps/src/mainQt.cpp:257-265).
  *   renderVolume / renderTrack / renderDepth shade on the device and copy the RGBW image out.
@@ -24,67 +25,24 @@
 #ifndef SE_HIP_DENSESLAMSYSTEM_H
 #define SE_HIP_DENSESLAMSYSTEM_H
 
+#include <algorithm>
 #include <cstdint>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../se_hip.h"
 
-#if defined(__has_include)
-#if __has_include(<Eigen/Dense>)
-#include <Eigen/Dense>
-#define SE_HIP_HAVE_EIGEN 1
-#endif
-#endif
-#ifndef SE_HIP_HAVE_EIGEN
-/* Eigen is not installed: minimal PODs with the storage layout and the few accessors the
- * DenseSLAMSystem interface needs (column-major Matrix4f, .data(), operator()). */
-namespace Eigen {
-template <typename T, int N> struct SeVec {
-  T v[N];
-  SeVec() : v() {}
-  SeVec(T a, T b) { static_assert(N == 2, ""); v[0] = a; v[1] = b; }
-  SeVec(T a, T b, T c) { static_assert(N == 3, ""); v[0] = a; v[1] = b; v[2] = c; }
-  SeVec(T a, T b, T c, T d) { static_assert(N == 4, ""); v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
-  T& operator()(int i) { return v[i]; }
-  const T& operator()(int i) const { return v[i]; }
-  T x() const { return v[0]; }
-  T y() const { return v[1]; }
-  T z() const { return v[2]; }
-  T w() const { return v[3]; }
-  const T* data() const { return v; }
-};
-typedef SeVec<int, 2> Vector2i;
-typedef SeVec<int, 3> Vector3i;
-typedef SeVec<float, 3> Vector3f;
-typedef SeVec<float, 4> Vector4f;
-struct Matrix4f {
-  float m[16];  // column-major
-  Matrix4f() : m() {}
-  static Matrix4f Identity() { Matrix4f a; a.m[0] = a.m[5] = a.m[10] = a.m[15] = 1.f; return a; }
-  float& operator()(int r, int c) { return m[c * 4 + r]; }
-  const float& operator()(int r, int c) const { return m[c * 4 + r]; }
-  const float* data() const { return m; }
-  float* data() { return m; }
-};
-}  // namespace Eigen
-#endif
+#include "config.h"       /* the reference's Configuration, field for field (+ hip_device, hip_max_blocks) */
+#include "eigen_pods.h"
+#include "octree.hpp"     /* SDF / OFusion field types, se::Octree<FieldType> host mirror for getMap() */
 
-struct SDF {};      /* field-type tags: se_denseslam/include/se/volume_traits.hpp:41-72 */
-struct OFusion {};
 #ifndef SE_FIELD_TYPE
 #error "define SE_FIELD_TYPE to SDF or OFusion before including se/DenseSLAMSystem.h (as the reference requires)"
 #endif
 typedef SE_FIELD_TYPE FieldType;
-
-/* the fields of the reference's Configuration (se_denseslam/include/se/config.h) this path reads */
-struct Configuration {
-  float mu = 0.1f;
-  int device = 0;
-  long long max_blocks = 0;
-};
 
 struct MapSnapshot {
   int n_blocks = 0, n_nodes = 0;
@@ -114,10 +72,15 @@ class DenseSLAMSystem {
     c.width = inputSize.x(); c.height = inputSize.y();
     c.volume_resolution = volumeResolution.x(); c.volume_dimension = volumeDimensions.x();
     c.field_type = is_sdf() ? SE_HIP_FIELD_SDF : SE_HIP_FIELD_OFUSION;
-    c.device = config.device; c.max_blocks = config.max_blocks;
+    c.device = config.hip_device; c.max_blocks = config.hip_max_blocks;
     if (se_hip_create(&c, &h_) != SE_HIP_OK) throw std::runtime_error(std::string("DenseSLAMSystem: ") + se_hip_last_error());
+    live().push_back(h_);
   }
-  ~DenseSLAMSystem() { se_hip_destroy(h_); }
+  ~DenseSLAMSystem() {
+    std::vector<se_hip_pipeline*>& l = live();
+    l.erase(std::remove(l.begin(), l.end(), h_), l.end());
+    se_hip_destroy(h_);
+  }
   DenseSLAMSystem(const DenseSLAMSystem&) = delete;
   DenseSLAMSystem& operator=(const DenseSLAMSystem&) = delete;
 
@@ -163,9 +126,44 @@ class DenseSLAMSystem {
 
   /* DenseSLAMSystem.h:224 / DenseSLAMSystem.cpp:302-322: marching cubes of the map into a VTK file */
   void dump_mesh(const std::string filename) { ok(se_hip_dump_mesh(h_, filename.c_str())); }
+  /* DenseSLAMSystem.h:219: declared, called by se_apps/src/benchmark.cpp:187, and EMPTY in the reference
+   * (DenseSLAMSystem.cpp:270-272) -- kept empty so that an application behaves the same; saveMap() is the useful thing */
+  void dump_volume(const std::string) {}
+  /* the whole map in Octree::save's byte layout, and back (Octree::load without its defects, see se_hip.h) */
+  bool saveMap(const std::string& filename) { return ok(se_hip_save_map(h_, filename.c_str())); }
+  bool loadMap(const std::string& filename) { return ok(se_hip_load_map(h_, filename.c_str())); }
   void setViewPose(Eigen::Matrix4f* value = NULL) { viewPose_ = value ? value : &pose_; }   /* DenseSLAMSystem.h:363-372 */
   Eigen::Matrix4f* getViewPose() { return viewPose_; }
 
+  /* DenseSLAMSystem.h:295: the reference shares its live se::Octree; here the device map is materialised as a host
+   * se::Octree<FieldType> (include/se/octree.hpp) with the reference's node / block member layout and read interface */
+  void getMap(std::shared_ptr<se::Octree<FieldType> >& out) {
+    out = std::make_shared<se::Octree<FieldType> >();
+    out->init(volume_resolution_.x(), volume_dimension_.x());
+    int nb = 0, nn = 0;
+    if (!ok(se_hip_counts(h_, &nb, &nn))) return;
+    std::vector<uint64_t> code(nn);
+    std::vector<uint32_t> side(nn);
+    std::vector<float> nx((size_t)nn * 8), ny((size_t)nn * 8);
+    if (!ok(se_hip_download_nodes(h_, code.data(), side.data(), nx.data(), ny.data()))) return;
+    for (int i = 0; i < nn; ++i) {
+      se::Node<FieldType>* n = out->add_node(code[i], side[i]);
+      for (int j = 0; j < 8; ++j) { n->value_[j].x = nx[(size_t)i * 8 + j]; n->value_[j].y = ny[(size_t)i * 8 + j]; }
+    }
+    MapSnapshot snap;
+    getMap(snap);
+    int max_level = 0;
+    for (int s = volume_resolution_.x(); s > 1; s >>= 1) ++max_level;
+    for (int i = 0; i < snap.n_blocks; ++i) {
+      const int* c = &snap.coords[(size_t)i * 3];
+      uint64_t key = 0;
+      for (int b = 0; b < max_level; ++b)
+        key |= ((uint64_t)((c[0] >> b) & 1) << (3 * b)) | ((uint64_t)((c[1] >> b) & 1) << (3 * b + 1)) | ((uint64_t)((c[2] >> b) & 1) << (3 * b + 2));
+      se::VoxelBlock<FieldType>* blk = out->add_block(key | (uint64_t)(max_level - 3), c, snap.active[i] != 0);
+      for (int v = 0; v < 512; ++v) { blk->voxel_block_[v].x = snap.x[(size_t)i * 512 + v]; blk->voxel_block_[v].y = snap.y[(size_t)i * 512 + v]; }
+    }
+    out->finalize();
+  }
   void getMap(MapSnapshot& out) {
     int nb = 0, nn = 0;
     if (!ok(se_hip_counts(h_, &nb, &nn))) return;
@@ -196,6 +194,8 @@ class DenseSLAMSystem {
   Eigen::Vector3i getModelResolution() { return volume_resolution_; }
   Eigen::Vector2i getComputationResolution() { return computation_size_; }
   se_hip_pipeline* handle() { return h_; }
+  /* every live pipeline of the process (what the argument-less synchroniseDevices() waits for) */
+  static std::vector<se_hip_pipeline*>& live() { static std::vector<se_hip_pipeline*> l; return l; }
 
  private:
   static bool is_sdf();
@@ -218,7 +218,6 @@ class DenseSLAMSystem {
   float mu_ = 0.1f;
   std::vector<int32_t> iterations_;
   bool tracked_ = false, integrated_ = false;
-  friend void synchroniseDevices();
 };
 
 namespace se_hip_detail {
@@ -227,7 +226,9 @@ template <> struct is_sdf_tag<SDF> { static const bool value = true; };
 }  // namespace se_hip_detail
 inline bool DenseSLAMSystem::is_sdf() { return se_hip_detail::is_sdf_tag<FieldType>::value; }
 
-/* declared and never defined in the reference (DenseSLAMSystem.h:418) */
+/* void synchroniseDevices(): declared and never defined in the reference (DenseSLAMSystem.h:418).  Its body here: wait for
+ * everything every live DenseSLAMSystem of this process has enqueued on its device. */
+inline void synchroniseDevices() { for (se_hip_pipeline* h : DenseSLAMSystem::live()) se_hip_sync(h); }
 inline void synchroniseDevices(DenseSLAMSystem& s) { se_hip_sync(s.handle()); }
 
 #endif /* SE_HIP_DENSESLAMSYSTEM_H */

@@ -7,7 +7,7 @@
  * (se_denseslam/src/DenseSLAMSystem.cpp:191-268) do on the host.  The reference has no FFI of
  * its own (one process, header-only C++); each entry point below cites the reference
  * interface it replaces.  POD arguments only: the same shared library serves the C++
- * `DenseSLAMSystem` mirror (supereight_amd/csrc/DenseSLAMSystem.cpp), the ctypes binding
+ * `DenseSLAMSystem` mirror (include/se/DenseSLAMSystem.h, header-only), the ctypes binding
  * (supereight_amd/pipeline.py) and any other FFI.
  *
  * Conventions
@@ -58,6 +58,11 @@ typedef struct se_hip_config {
 } se_hip_config;
 
 int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out);
+/* The multi-device form of the constructor (device_ids[]): one row-sharded replica per listed device,
+ * replica i owning the i-th share of the image's 8-row tiles (cfg->device / row_begin / row_end are ignored).  The
+ * per-frame key-list exchange between the replicas is the caller's (se_hip_alloc_exchange, or se_hip_new_keys_device +
+ * se_hip_alloc_commit); one process per GPU with se_hip_create is the deployment this library is measured in. */
+int se_hip_create_replicas(const se_hip_config* cfg, const int32_t* device_ids, int32_t n_devices, se_hip_pipeline** out_handles);
 int se_hip_destroy(se_hip_pipeline* p);
 const char* se_hip_last_error(void);
 /* free function synchroniseDevices() is declared but never defined in the reference
@@ -80,7 +85,9 @@ int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m);
 /* mm2metersKernel fused into the upload (se_denseslam/src/preprocessing.cpp:161-188):
  * uint16 millimetres of size (in_w, in_h), an integer multiple of the computation size. */
 int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_depth_mm, int32_t in_w, int32_t in_h);
-/* Zero-copy: integrate from a depth image already resident in HBM (width*height floats). */
+/* Zero-copy: integrate from a depth image already resident in HBM (width*height floats).  The buffer is read by the
+ * allocation scan and by the integration sweep of the frame: it must stay untouched until that sweep has finished
+ * (se_hip_sync, or work ordered behind se_hip_integrate on the handle's stream). */
 int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m);
 
 /* ---- bool DenseSLAMSystem::integration(const Vector4f& k, unsigned integration_rate, float mu,
@@ -104,8 +111,11 @@ int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* 
 /* Make the scan write its list into caller-owned device memory (e.g. the send buffer of the RCCL
  * allgather); capacity_words includes the count word.  NULL restores the internal buffer. */
 int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_t capacity_words);
-/* The lists must have been produced by work ordered on the scan stream (se_hip_set_scan_stream) or on the
- * main stream; the call joins the scan stream into the main stream before it reads them. */
+/* The lists must have been produced by work ordered on the stream the allocation scan runs on: the scan stream
+ * (se_hip_set_scan_stream) when se_hip_scan_overlaps() is 1 -- the commit kernel is launched there, behind the scan and
+ * the caller's all-gather, beside the previous frame's raycast -- and the main stream otherwise.  A new-key list that
+ * overflowed (more keys than its capacity) makes the next stage call fail with SE_HIP_E_CAPACITY: the replicas would
+ * diverge otherwise. */
 int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_t nlists, int64_t stride_words);
 /* Multi-GPU exchange without a host framework in the per-frame path: `nccl_comm` is the ncclComm_t of the caller's
  * communicator (RCCL), `nccl_all_gather` the address of ncclAllGather in the RCCL the process has loaded (the library
@@ -170,13 +180,18 @@ int se_hip_download_nodes(se_hip_pipeline* p, uint64_t* code, uint32_t* side, fl
  *      Nodes and blocks are written sorted by key (the reference writes its pool order, which is
  *      nondeterministic under OpenMP). */
 int se_hip_save_map(se_hip_pipeline* p, const char* filename);
+/* Octree::load (se_core/include/se/octree.hpp:917-950): re-initialises the device map and restores it from a file in
+ * the layout above (written by se_hip_save_map or by the reference's Octree::save) for the same size / dim / field
+ * type.  The reference's load() reads `dim` as an int and restores one voxel per block (octree.hpp:921-924, 945-946);
+ * this one reads the float and restores all 512.  Blocks come back active, as Octree::insert leaves them. */
+int se_hip_load_map(se_hip_pipeline* p, const char* filename);
 
 /* ---- map export, second half: marching cubes over the allocated blocks
  * DenseSLAMSystem::dump_mesh (DenseSLAMSystem.cpp:302-322) = se::algorithms::marching_cube
  * (se_core/include/se/algorithms/meshing.hpp:161-208) with inside(v) = v.x < 0, select(v) = v.x, then writeVtkMesh
  * (se_denseslam/include/se/commons.h:325-390).  Vertices (which cell edges carry one, and where) are the
- * reference's; the split of a cell's polygon into triangles follows include/se_mc_table.h, a derived table, not the
- * reference's edge_tables.h.  A triangle is 9 floats (3 vertices, metres); their order is unspecified, as in the
+ * reference's, and so is the split of a cell's polygon into triangles: include/se_mc_table.h is the standard marching-cubes
+ * table, content-identical to the reference's edge_tables.h:66 (tests/test_mc_table_reference.py).  A triangle is 9 floats (3 vertices, metres); their order is unspecified, as in the
  * reference (OpenMP completion order there). */
 int se_hip_mesh_count(se_hip_pipeline* p, int64_t* n_triangles);
 int se_hip_mesh_download(se_hip_pipeline* p, float* host_triangles, int64_t capacity_triangles, int64_t* n_written);

@@ -98,6 +98,7 @@ struct se_hip_pipeline {
   size_t tab_entries = 0;
   size_t occ_words = 0;
   size_t slots = 0;
+  size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
   float* depth_own = nullptr;       // width*height floats
   const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
@@ -380,7 +381,42 @@ int check(se_hip_pipeline* p) {
   return SE_HIP_OK;
 }
 
+// The sweep kernel mirrors the device counters into pinned memory when it starts, so an overflow raised by a scan /
+// commit is visible to the host by the next stage call without any synchronisation: the frame path reports it
+// (a frame late at most) instead of carrying on with a truncated key list or a map that lost octants.
+int check_overflow(se_hip_pipeline* p) {
+  const uint32_t o = p->ctr_host[C_OVERFLOW];
+  if (o) return fail(SE_HIP_E_CAPACITY, o == 2 ? "new-key list overflow: blocks were allocated locally but not reported to the peers (raise the exchange capacity)"
+                                              : "block / node pool exhausted (raise max_blocks)");
+  return SE_HIP_OK;
+}
+
 bool stage_runs_integration(uint32_t frame, uint32_t rate) { return ((frame % rate) == 0) || (frame <= 3); }
+
+// Octree::init (se_core/include/se/octree.hpp:425-437) on the device: empty index, root node, every brick and node value
+// at initValue().  Enqueued on the main stream.
+void reset_map_state(se_hip_pipeline* p) {
+  DevMap& m = p->map;
+  const size_t cells = (size_t)1 << (3 * p->leaf_level);
+  hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.lbits, 0, ((cells + 31) / 32) * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
+  hipMemsetAsync(m.npos, 0, p->cap_nodes * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.nlevel, 0, p->cap_nodes, p->stream);
+  hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
+  hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), p->stream);
+  // node 0 = root: level 0, side = size
+  const uint32_t ctr0[C_COUNT] = {0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u};
+  hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
+  std::memset(p->ctr_host, 0, C_COUNT * sizeof(uint32_t));
+  p->ctr_host[C_NODES] = 1u;
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vx, m.init_x, p->slots * 512);
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vy, m.init_y, p->slots * 512);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.nx, m.init_x, p->cap_nodes * 8);
+  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.ny, m.init_y, p->cap_nodes * 8);
+}
 
 int grid_for(size_t n, int wg, int cap) { size_t g = (n + wg - 1) / wg; if (g < 1) g = 1; if (g > (size_t)cap) g = cap; return (int)g; }
 
@@ -492,26 +528,13 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->depth = p->depth_own;
   e = hipHostMalloc((void**)&p->ctr_host, C_COUNT * sizeof(uint32_t));
   if (e != hipSuccess) return bail(e, "hipHostMalloc");
+  std::memset(p->ctr_host, 0, C_COUNT * sizeof(uint32_t));
 
-  hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.lbits, 0, ((cells + 31) / 32) * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.bpos, 0, cap * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.bactive, 0, slots, p->stream);
-  hipMemsetAsync(m.npos, 0, capn * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.nlevel, 0, capn, p->stream);
-  hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
-  hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), p->stream);
+  p->cap_blocks = cap; p->cap_nodes = capn;
+  reset_map_state(p);
   hipMemsetAsync(p->depth_own, 0, (size_t)cfg->width * cfg->height * sizeof(float), p->stream);
   hipMemsetAsync(p->vertex, 0, (size_t)cfg->width * cfg->height * 3 * sizeof(float), p->stream);
   hipMemsetAsync(p->normal, 0, (size_t)cfg->width * cfg->height * 3 * sizeof(float), p->stream);
-  // node 0 = root (Octree::init, se_core/include/se/octree.hpp:425-437): level 0, side = size
-  const uint32_t ctr0[C_COUNT] = {0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u};
-  hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
-  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vx, m.init_x, slots * 512);
-  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vy, m.init_y, slots * 512);
-  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.nx, m.init_x, capn * 8);
-  hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.ny, m.init_y, capn * 8);
   if (cfg->field_type == SE_HIP_FIELD_OFUSION) {
     std::vector<float> lut, lo;
     make_bspline(lut);
@@ -562,7 +585,7 @@ int se_hip_sync(se_hip_pipeline* p) {
   if (int r = check(p)) return r;
   if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   HIP_TRY(hipStreamSynchronize(p->stream));
-  return SE_HIP_OK;
+  return check_overflow(p);
 }
 
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
@@ -799,6 +822,7 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   if (int r = check(p)) return r;
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!stage_runs_integration(frame, rate)) return 0;
+  if (int r = check_overflow(p)) return r;
   if (int r = join_scan(p, true)) return r;
   const DevMap& m = p->map;
   const M4 pose = from_colmajor(pose_cm);
@@ -872,6 +896,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (int r = check(p)) return r;
   if (!pose_cm || !k) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!(frame > 2)) return 0;  // DenseSLAMSystem.cpp:195
+  if (int r = check_overflow(p)) return r;
   if (int r = join_scan(p)) return r;
   std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   const DevMap& m = p->map;
@@ -951,6 +976,12 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     Gauss5 G;
     for (unsigned int i = 0; i < 5; i++) { const int x = (int)i - 2; G.g[i] = expf(-(x * x) / (2 * 4.0f * 4.0f)); }
     hipLaunchKernelGGL(k_bilateral_filter, dim3((W + 255) / 256, H), dim3(256), 0, s, p->pyr_depth[0], d0, W, H, G, 0.1f);
+    d0 = p->pyr_depth[0];
+  }
+  if (!p->filter_input) {
+    // scaled_depth_[0] is a copy of float_depth_ in the reference too (DenseSLAMSystem.cpp:149-152): the tracker's level 0
+    // must not alias an input buffer that the next upload (or the caller, for zero-copy depth) may overwrite
+    HIP_TRY(hipMemcpyAsync(p->pyr_depth[0], d0, (size_t)W * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     d0 = p->pyr_depth[0];
   }
   p->scaled0 = d0;
@@ -1311,6 +1342,111 @@ int se_hip_save_map(se_hip_pipeline* p, const char* filename) {
   const bool okw = std::ferror(f) == 0;
   std::fclose(f);
   return okw ? SE_HIP_OK : fail(SE_HIP_E_INVALID, "write error");
+}
+
+// Octree::load (se_core/include/se/octree.hpp:917-950) for the device map: reads the byte layout of Octree::save /
+// se_hip_save_map, re-initialises the map (the reference's load() calls init()), inserts every node and block and
+// restores their values.  Two defects of the reference's load() are NOT reproduced: it reads `dim` into an int (the file
+// holds a float, octree.hpp:921-924) and it copies only the first voxel of every block (sizeof(*getBlockRawPtr()),
+// octree.hpp:945-946); here `dim` is read as the float it is and all 512 voxels are restored.  As in the reference,
+// blocks come back with active_ = true (Octree::insert, octree.hpp:518).  The file must have been written for the same
+// volume (size, dim) and field type as this handle.
+int se_hip_load_map(se_hip_pipeline* p, const char* filename) {
+  if (int r = check(p)) return r;
+  if (!filename) return fail(SE_HIP_E_INVALID, "bad argument");
+  FILE* f = std::fopen(filename, "rb");
+  if (!f) return fail(SE_HIP_E_INVALID, std::string("cannot open ") + filename);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  const size_t vbytes = sdf ? 8 : 16;
+  int32_t size = 0; float dim = 0.f; uint64_t nn = 0, nb = 0;
+  bool okr = std::fread(&size, 4, 1, f) == 1 && std::fread(&dim, 4, 1, f) == 1 && std::fread(&nn, 8, 1, f) == 1;
+  if (!okr || size != p->map.size || dim != p->map.dim) { std::fclose(f); return fail(SE_HIP_E_INVALID, "map file does not match this volume (size / dim)"); }
+  if (nn > p->cap_nodes) { std::fclose(f); return fail(SE_HIP_E_CAPACITY, "map file holds more nodes than the pool"); }
+  auto get_values = [&](size_t count, float* x, float* y) -> bool {
+    std::vector<unsigned char> raw(count * vbytes);
+    if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) return false;
+    for (size_t i = 0; i < count; ++i) {
+      std::memcpy(&x[i], &raw[i * vbytes], 4);
+      if (sdf) std::memcpy(&y[i], &raw[i * vbytes + 4], 4);
+      else { double d; std::memcpy(&d, &raw[i * vbytes + 8], 8); y[i] = (float)d; }
+    }
+    return true;
+  };
+  std::vector<unsigned long long> keys; keys.reserve((size_t)nn + 1);
+  std::vector<float> nx((size_t)nn * 8), ny((size_t)nn * 8);
+  for (uint64_t i = 0; i < nn && okr; ++i) {
+    unsigned long long code = 0; int32_t side = 0;
+    okr = std::fread(&code, 8, 1, f) == 1 && std::fread(&side, 4, 1, f) == 1 && get_values(8, &nx[i * 8], &ny[i * 8]);
+    keys.push_back(code);
+  }
+  okr = okr && std::fread(&nb, 8, 1, f) == 1;
+  if (okr && nb > p->cap_blocks) { std::fclose(f); return fail(SE_HIP_E_CAPACITY, "map file holds more blocks than the pool (raise max_blocks)"); }
+  std::vector<int32_t> coords((size_t)nb * 3);
+  std::vector<float> bx((size_t)nb * 512), by((size_t)nb * 512);
+  std::vector<unsigned long long> bkeys((size_t)nb);
+  for (uint64_t i = 0; i < nb && okr; ++i) {
+    okr = std::fread(&bkeys[i], 8, 1, f) == 1 && std::fread(&coords[i * 3], 4, 3, f) == 3 && get_values(512, &bx[i * 512], &by[i * 512]);
+    if (okr) for (int c = 0; c < 3; ++c) okr = okr && coords[i * 3 + c] >= 0 && coords[i * 3 + c] < size && (coords[i * 3 + c] & 7) == 0;
+  }
+  std::fclose(f);
+  if (!okr) return fail(SE_HIP_E_INVALID, "truncated or malformed map file");
+  // quiesce, re-initialise, insert
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->scan_pending = false; p->occ_commit_due = false; p->occ_lists = OccLists{nullptr, 0, 0};
+  reset_map_state(p);
+  std::vector<unsigned long long> list;
+  list.reserve(1 + keys.size() + bkeys.size());
+  list.push_back(0ull);
+  for (unsigned long long kx : keys) if ((kx & 0x1FFull) != 0ull) list.push_back(kx);   // (the root, key 0, exists already)
+  for (uint64_t i = 0; i < nb; ++i)
+    list.push_back(se_make_key(coords[i * 3] >> 3, coords[i * 3 + 1] >> 3, coords[i * 3 + 2] >> 3, p->leaf_level, p->max_level));
+  list[0] = list.size() - 1;
+  unsigned long long* d_list = nullptr; float *d_x = nullptr, *d_y = nullptr; int32_t* d_c = nullptr; unsigned long long* d_k = nullptr;
+  auto cleanup = [&]() { for (void* q : {(void*)d_list, (void*)d_x, (void*)d_y, (void*)d_c, (void*)d_k}) if (q) hipFree(q); };
+  const size_t nval = std::max((size_t)nb * 512, (size_t)nn * 8) + 8;
+  if (hipMalloc((void**)&d_list, list.size() * 8) != hipSuccess || hipMalloc((void**)&d_x, nval * 4) != hipSuccess || hipMalloc((void**)&d_y, nval * 4) != hipSuccess ||
+      hipMalloc((void**)&d_c, ((size_t)nb * 3 + 4) * 4) != hipSuccess || hipMalloc((void**)&d_k, ((size_t)nn + 1) * 8) != hipSuccess) { cleanup(); return fail(SE_HIP_E_DEVICE, "hipMalloc (load staging)"); }
+  hipMemcpyAsync(d_list, list.data(), list.size() * 8, hipMemcpyHostToDevice, p->stream);
+  hipLaunchKernelGGL(k_alloc_commit, dim3(256, 1), dim3(SE_WG), 0, p->stream, p->map, d_list, 1, (long long)list.size());
+  if (nn) {
+    hipMemcpyAsync(d_k, keys.data(), (size_t)nn * 8, hipMemcpyHostToDevice, p->stream);
+    hipMemcpyAsync(d_x, nx.data(), (size_t)nn * 8 * 4, hipMemcpyHostToDevice, p->stream);
+    hipMemcpyAsync(d_y, ny.data(), (size_t)nn * 8 * 4, hipMemcpyHostToDevice, p->stream);
+    hipLaunchKernelGGL(k_load_nodes, dim3(grid_for((size_t)nn * 8, SE_WG, 4096)), dim3(SE_WG), 0, p->stream, p->map, d_k, d_x, d_y, (size_t)nn);
+    hipStreamSynchronize(p->stream);   // the staging buffers are reused for the blocks
+  }
+  if (nb) {
+    hipMemcpyAsync(d_c, coords.data(), (size_t)nb * 3 * 4, hipMemcpyHostToDevice, p->stream);
+    hipMemcpyAsync(d_x, bx.data(), (size_t)nb * 512 * 4, hipMemcpyHostToDevice, p->stream);
+    hipMemcpyAsync(d_y, by.data(), (size_t)nb * 512 * 4, hipMemcpyHostToDevice, p->stream);
+    hipLaunchKernelGGL(k_load_blocks, dim3(grid_for((size_t)nb * 512, SE_WG, 16384)), dim3(SE_WG), 0, p->stream, p->map, d_c, d_x, d_y, (size_t)nb);
+  }
+  const hipError_t e = hipStreamSynchronize(p->stream);
+  cleanup();
+  if (e != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("load_map: ") + hipGetErrorString(e));
+  int32_t gb = 0, gn = 0;
+  if (int r = se_hip_counts(p, &gb, &gn)) return r;
+  if ((uint64_t)gb != nb || (uint64_t)gn != nn) return fail(SE_HIP_E_INVALID, "map file is not ancestor-closed (octants without parents) or holds duplicates");
+  return SE_HIP_OK;
+}
+
+// DenseSLAMSystem::dump_volume (DenseSLAMSystem.h:219) has an empty body in the reference (DenseSLAMSystem.cpp:270-272); the
+// useful thing behind the name -- the whole volume on disk -- is se_hip_save_map.
+
+int se_hip_create_replicas(const se_hip_config* cfg, const int32_t* device_ids, int32_t n_devices, se_hip_pipeline** out_handles) {
+  if (!cfg || !device_ids || !out_handles || n_devices < 1) return fail(SE_HIP_E_INVALID, "bad argument");
+  const int units = (cfg->height + 7) / 8;
+  for (int i = 0; i < n_devices; ++i) out_handles[i] = nullptr;
+  for (int i = 0; i < n_devices; ++i) {
+    se_hip_config c = *cfg;
+    c.device = device_ids[i];
+    c.row_begin = std::min(cfg->height, 8 * ((units * i) / n_devices));
+    c.row_end = (i + 1 == n_devices) ? cfg->height : std::min(cfg->height, 8 * ((units * (i + 1)) / n_devices));
+    const int r = (c.row_end > c.row_begin) ? se_hip_create(&c, &out_handles[i]) : fail(SE_HIP_E_INVALID, "more devices than 8-row image tiles");
+    if (r != SE_HIP_OK) { const std::string msg = g_err; for (int j = 0; j < i; ++j) { se_hip_destroy(out_handles[j]); out_handles[j] = nullptr; } return fail(r, msg); }
+  }
+  return SE_HIP_OK;
 }
 
 // --------------------------------------------------------------------------------- measurement

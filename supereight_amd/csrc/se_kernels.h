@@ -42,7 +42,7 @@ __device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, 
     const uint32_t old = atomicCAS(e, 0u, SE_PENDING);
     if (old != 0u) break;
     const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
-    if (nid >= m.cap_nodes) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); break; }
+    if (nid >= m.cap_nodes) { atomicSub(&m.ctr[C_NODES], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); break; }   // counter stays bounded; reported by the next API call (SE_HIP_E_CAPACITY)
     m.npos[nid] = pack_pos(x, y, z);
     m.nlevel[nid] = (uint8_t)l;
     occ_set(m, l, x, y, z);
@@ -58,7 +58,7 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
   if (old != 0u) return false;
   if (level == m.leaf_level) {
     const uint32_t idx = atomicAdd(&m.ctr[C_BLOCKS], 1u);
-    if (idx >= m.cap_blocks) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
+    if (idx >= m.cap_blocks) { atomicSub(&m.ctr[C_BLOCKS], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
     const uint32_t bp = pack_pos(x, y, z);
     const uint32_t slot = block_slot(m, idx, bp);
     m.bpos[idx] = bp;
@@ -69,7 +69,7 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
     atomicExch(e, slot + 1u);
   } else {
     const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
-    if (nid >= m.cap_nodes) { m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
+    if (nid >= m.cap_nodes) { atomicSub(&m.ctr[C_NODES], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
     m.npos[nid] = pack_pos(x, y, z);
     m.nlevel[nid] = (uint8_t)level;
     occ_set(m, level, x, y, z);
@@ -1458,6 +1458,35 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
 __global__ __launch_bounds__(SE_WG) void k_gather_bricks(const float* __restrict__ plane, const uint32_t* __restrict__ slots, size_t n, float* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 512; i += (size_t)gridDim.x * SE_WG)
     out[i] = plane[(size_t)slots[i >> 9] * 512 + (i & 511)];
+}
+// se_hip_load_map: values of the octants of a map file -> device planes (the octants were inserted by k_alloc_commit before)
+__global__ __launch_bounds__(SE_WG) void k_load_nodes(DevMap m, const unsigned long long* __restrict__ keys, const float* __restrict__ x, const float* __restrict__ y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 8; i += (size_t)gridDim.x * SE_WG) {
+    const unsigned long long key = keys[i >> 3];
+    const int level = (int)(key & 0x1FFull);
+    uint32_t nid = 0u;   // key 0 = the root
+    if (level != 0) {
+      if (level >= m.leaf_level) continue;
+      const unsigned long long code = key & ~0x1FFull;
+      const int sh = m.max_level - level;
+      const int px = (int)(se_compact21(code) >> sh), py = (int)(se_compact21(code >> 1) >> sh), pz = (int)(se_compact21(code >> 2) >> sh);
+      const uint32_t e = m.tab[tab_index(m, level, px, py, pz)];
+      if (e == 0u || e == SE_PENDING) continue;
+      nid = e - 1u;
+    }
+    m.nx[(size_t)nid * 8 + (i & 7)] = x[i];
+    m.ny[(size_t)nid * 8 + (i & 7)] = y[i];
+  }
+}
+__global__ __launch_bounds__(SE_WG) void k_load_blocks(DevMap m, const int* __restrict__ coords, const float* __restrict__ x, const float* __restrict__ y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 512; i += (size_t)gridDim.x * SE_WG) {
+    const size_t b = i >> 9;
+    const int bx = coords[3 * b] >> 3, by = coords[3 * b + 1] >> 3, bz = coords[3 * b + 2] >> 3;
+    const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
+    if (e == 0u || e == SE_PENDING) continue;
+    m.vx[(size_t)(e - 1u) * 512 + (i & 511)] = x[i];
+    m.vy[(size_t)(e - 1u) * 512 + (i & 511)] = y[i];
+  }
 }
 // pool initialisation: every voxel / node value starts at voxel_traits<T>::initValue()
 __global__ void k_fill(float* __restrict__ p, float v, size_t n) {

@@ -65,6 +65,8 @@ EXPORTS = {
     "se_hip_render_depth": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_render_track": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_save_map": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "se_hip_load_map": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "se_hip_create_replicas": (C.c_int, [C.POINTER(_Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     "se_hip_mesh_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "se_hip_mesh_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "se_hip_dump_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -320,6 +322,10 @@ class DenseSLAMPipeline:
     def save(self, filename: str):
         """Octree::save of the reference (octree.hpp:898-914): same byte layout, entries sorted by key."""
         self._check(self.lib.se_hip_save_map(self._h, filename.encode()))
+
+    def load(self, filename: str):
+        """Octree::load counterpart (octree.hpp:917-950, minus its two defects): the map becomes what the file holds."""
+        self._check(self.lib.se_hip_load_map(self._h, filename.encode()))
 
     # ------------------------------------------------------------------ measurement
     def enable_timing(self, on: bool = True):

@@ -45,4 +45,12 @@ def test_cpp_mirror_matches_ctypes_path(tmp_path, field, exe, mu):
     assert (vn[: W * H * 3].view(np.uint32) == v.reshape(-1).view(np.uint32)).all()
     assert (vn[W * H * 3:].view(np.uint32) == n.reshape(-1).view(np.uint32)).all()
     assert f"blocks {nb} nodes {nn}" in r.stdout
+    # getMap() as a host se::Octree (include/se/octree.hpp): complete, consistent, and its save() writes the bytes of
+    # se_hip_save_map; a second DenseSLAMSystem restored with loadMap() raycasts the same images
+    assert f"octree blocks {nb} nodes {nn} fetch_bad 0" in r.stdout and "reload_identical 1" in r.stdout
+    assert "coarse_checked 0" not in r.stdout
+    ref = str(tmp_path / "ref.bin")
+    p.save(ref)
+    assert open(out + ".octree", "rb").read() == open(ref, "rb").read()
+    assert open(out + ".devmap", "rb").read() == open(ref, "rb").read()
     p.close()

@@ -19,8 +19,13 @@ CASES = [
     ("sdf_160x120_256", SDF, 160, 120, 256, 2.4, 0.1, 6),
     ("sdf_640x480_512", SDF, 640, 480, 512, 4.8, 0.1, 6),       # BASELINE.json configs[1]
     ("sdf_320x240_1024", SDF, 320, 240, 1024, 4.8, 0.1, 5),     # configs[2] geometry, smaller image
+    ("sdf_640x480_1024", SDF, 640, 480, 1024, 4.8, 0.1, 4),     # configs[2] geometry at full image size
+    ("sdf_160x120_2048", SDF, 160, 120, 2048, 4.8, 0.1, 4),     # configs[3] volume: two occupancy levels beyond the LDS-staged ones
     ("ofusion_160x120_256", OFUSION, 160, 120, 256, 2.4, 0.02, 6),
     ("ofusion_640x480_512", OFUSION, 640, 480, 512, 4.8, 0.008, 5),   # configs[4], the reference's own ofusion mu (Makefile:39)
+    # the widest band whose key buffer the reference does not truncate at this size (mu = 0.1 saturates it on frame 0):
+    # long free-space rays, coarse (leaf-1 / leaf-2) octants hit hard
+    ("ofusion_640x480_512_mu005", OFUSION, 640, 480, 512, 4.8, 0.05, 4),
     # ICL-NUIM camera convention of configs[0] / configs[2] (-k 481.2,-480,320,240: negative fy)
     ("icl_like_sdf_320x240_512", SDF, 320, 240, 512, 4.8, 0.1, 5),
     ("icl_like_ofusion_160x120_256", OFUSION, 160, 120, 256, 2.4, 0.02, 5),

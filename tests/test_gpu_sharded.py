@@ -13,10 +13,12 @@ from supereight_amd.synthetic import SyntheticStream
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("field,mu,R", [(SDF, 0.1, 2), (SDF, 0.1, 4), (OFUSION, 0.02, 2)], ids=["sdf-2", "sdf-4", "ofusion-2"])
-def test_sharded_replicas_equal_single(field, mu, R):
+@pytest.mark.parametrize("field,mu,R,H", [(SDF, 0.1, 2, 120), (SDF, 0.1, 4, 120), (OFUSION, 0.02, 2, 120), (SDF, 0.1, 8, 116), (OFUSION, 0.02, 8, 116)],
+                         ids=["sdf-2", "sdf-4", "ofusion-2", "sdf-8-odd-height", "ofusion-8-odd-height"])
+def test_sharded_replicas_equal_single(field, mu, R, H):
+    # H = 116: 14.5 raycast tiles of 8 rows -> shards of 1 or 2 tile rows, the last one ending in a half tile
     import torch
-    W, H, N, dim, frames = 160, 120, 256, 2.4, 6
+    W, N, dim, frames = 160, 256, 2.4, 6
     dev = torch.device("cuda", 0)
     stream = SyntheticStream(W, H, dim)
     single = DenseSLAMPipeline((W, H), N, dim, field_type=field)
@@ -62,6 +64,27 @@ def test_sharded_replicas_equal_single(field, mu, R):
         p.close()
     assert (vs.view(np.uint32) == v.view(np.uint32)).all() and (ns.view(np.uint32) == n.view(np.uint32)).all()
     single.close()
+
+
+def test_key_list_overflow_is_reported_on_the_frame_path():
+    """A key list that does not fit its exchange buffer must not go unnoticed: the peers would miss blocks and the
+    replicas would diverge.  The stage calls of the following frame fail with SE_HIP_E_CAPACITY."""
+    import torch
+    from supereight_amd.pipeline import SeHipError
+    W, H, N, dim, mu = 160, 120, 256, 2.4, 0.1
+    stream = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim, field_type=SDF, rows=(0, 64))
+    words = 64                                      # frame 0 allocates ~1000 blocks in these rows
+    send = torch.zeros(words, dtype=torch.int64, device="cuda")
+    p.set_new_keys_buffer(send.data_ptr(), words, keepalive=send)
+    with pytest.raises(SeHipError, match="key list overflow"):
+        for f in range(3):
+            p.set_depth(stream.depth(f)); p.setPose(stream.pose(f))
+            p.alloc_scan(stream.k, 1, mu, f)
+            p.alloc_commit(send.data_ptr(), 1, words)
+            p.integrate_sweep(stream.k, 1, mu, f)
+            p.sync()
+    p.close()
 
 
 @pytest.mark.parametrize("exchange", ["direct", "torch"])

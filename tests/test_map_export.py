@@ -57,3 +57,59 @@ def test_hip_dump_equals_oracle_dump(tmp_path, field, name, mu):
         assert (np.diff(tb["code"].astype(np.int64)) > 0).all()          # the HIP dump is key-sorted
         assert ta.tobytes() == tb.tobytes()
     p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,name,mu,pooled", [(SDF, "sdf", 0.1, False), (OFUSION, "ofusion", 0.02, False), (SDF, "sdf", 0.1, True)],
+                         ids=["sdf", "ofusion", "sdf-pooled"])
+def test_hip_load_map_round_trip(tmp_path, field, name, mu, pooled):
+    """se_hip_load_map = Octree::load (octree.hpp:917-950) without its two defects: a map written by the ORACLE's
+    Octree::save restatement is loaded into a fresh device map, which must then hold that map (every node, block and
+    voxel), raycast like the pipeline that built it, and save to the same bytes."""
+    from supereight_amd.pipeline import DenseSLAMPipeline, SeHipError
+    o = build_cpu(field, mu, frames=5)
+    s = SyntheticStream(W, H, DIM)
+    kw = {"max_blocks": 4000} if pooled else {}
+    built = DenseSLAMPipeline((W, H), N, DIM, field_type=field, **kw)
+    for f in range(5):
+        built.set_depth(s.depth(f)); built.setPose(s.pose(f))
+        built.integration(s.k, 1, mu, f)
+        built.raycasting(s.k, mu, f)
+    pa, pb = str(tmp_path / "cpu.bin"), str(tmp_path / "gpu.bin")
+    assert o.save(pa)
+    loaded = DenseSLAMPipeline((W, H), N, DIM, field_type=field, **kw)
+    s0 = SyntheticStream(W, H, DIM)
+    loaded.set_depth(s0.depth(0)); loaded.setPose(s0.pose(0)); loaded.integration(s0.k, 1, mu, 0)   # something to be wiped
+    loaded.load(pa)
+    c, x, y, a = o.blocks()
+    lc, lx, ly, la = loaded.blocks()
+    assert len(c) > 300 and lc.shape == c.shape and (lc == c).all()
+    assert (lx.view(np.uint32) == x.view(np.uint32)).all() and (ly.view(np.uint32) == y.view(np.uint32)).all()
+    assert (la == 1).all()                                               # Octree::insert: active(true)
+    code, side, nx, ny = o.nodes()
+    lcode, lside, lnx, lny = loaded.nodes()
+    assert (lcode == code).all() and (lside == side).all()
+    assert (lnx.view(np.uint32) == nx.view(np.uint32)).all() and (lny.view(np.uint32) == ny.view(np.uint32)).all()
+    loaded.save(pb)
+    built.save(str(tmp_path / "built.bin"))
+    assert open(pb, "rb").read() == open(str(tmp_path / "built.bin"), "rb").read()
+    # the restored index drives the ray traversal: same images as the pipeline that integrated the frames
+    pose = SyntheticStream(W, H, DIM).pose(4)
+    loaded.setPose(pose); loaded.raycasting(s.k, mu, 4)
+    v0, n0 = built.vertex_normal()
+    v1, n1 = loaded.vertex_normal()
+    assert (n0[..., 0] != -2).sum() > 1000
+    assert (v0.view(np.uint32) == v1.view(np.uint32)).all() and (n0.view(np.uint32) == n1.view(np.uint32)).all()
+    # and the map stays usable: one more frame on both
+    d5, p5 = s.depth(5), s.pose(5)
+    for q in (built, loaded):
+        q.set_depth(d5); q.setPose(p5); q.integration(s.k, 1, mu, 5); q.raycasting(s.k, mu, 5)
+    b0, b1 = built.blocks(), loaded.blocks()
+    assert (b0[0] == b1[0]).all() and (b0[1].view(np.uint32) == b1[1].view(np.uint32)).all() and (b0[2].view(np.uint32) == b1[2].view(np.uint32)).all()
+    v0, n0 = built.vertex_normal(); v1, n1 = loaded.vertex_normal()
+    assert (v0.view(np.uint32) == v1.view(np.uint32)).all()
+    # a file for another volume is refused
+    other = DenseSLAMPipeline((W, H), 2 * N, DIM, field_type=field)
+    with pytest.raises(SeHipError, match="does not match"):
+        other.load(pa)
+    other.close(); built.close(); loaded.close()

@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-OURS = ("k_alloc", "k_integrate", "k_raycast", "k_fill", "k_min_key", "k_zero_chain", "k_mm2meters")
+OURS = ("k_alloc", "k_integrate", "k_raycast", "k_fill", "k_occ_commit", "k_zero_chain", "k_mm2meters")
 
 
 def short(name):
@@ -24,7 +24,8 @@ def find(sub, pattern):
     return sorted(glob.glob(os.path.join(out_dir, sub, "**", pattern), recursive=True))
 
 
-print(f"# rocprofv3 summary `{tag}`  (bench.py --steps 50 --warmup 10, MI355X)\n")
+LAST = int(os.environ.get("SE_PROF_LAST", 50))   # launches per kernel that belong to the timed region (= bench.py --steps; the prewarm / warm-up launches come first)
+print(f"# rocprofv3 summary `{tag}`  (bench.py --steps {LAST} --warmup 10 --no-modes --sustain 0, MI355X; per-kernel figures = the last {LAST} launches)\n")
 stats = find("trace", "*kernel_stats.csv")
 if stats:
     print("## kernel trace (--kernel-trace --stats)\n")
@@ -44,12 +45,12 @@ if trace:
     with open(trace[0]) as fh:
         for row in csv.DictReader(fh):
             dur[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
-    print("## steady state (launches after the 14 warm-up frames, from the raw kernel trace)\n")
+    print(f"## timed region (the last {LAST} launches of each kernel, from the raw kernel trace)\n")
     print("| kernel | launches | avg us | p50 us | p95 us |")
     print("|---|---|---|---|---|")
     for k, v in sorted(dur.items()):
         v.sort()
-        d = sorted(x[1] for x in v[14:]) or sorted(x[1] for x in v)
+        d = sorted(x[1] for x in v[-LAST:])
         if not any(o in k for o in OURS):
             continue
         print(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {d[len(d) // 2] / 1e3:.2f} | {d[int(len(d) * 0.95)] / 1e3:.2f} |")
@@ -73,7 +74,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_cache"):
         n = 0
         for c in names:
             v = acc[k].get(c, [])
-            v = v[14:] if len(v) > 20 else v
+            v = v[-LAST:]
             n = max(n, len(v))
             cells.append(f"{sum(v) / len(v):.4g}" if v else "-")
         print(f"| {k} | {n} | " + " | ".join(cells) + " |")
@@ -94,7 +95,7 @@ for sub, dst in (("pmc_fetch", fetch), ("pmc_write", write)):
             if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     for k, v in acc.items():
-        v = v[14:] if len(v) > 20 else v
+        v = v[-LAST:]
         dst[k] = sum(v) / len(v)
 names = {"k_alloc_scan": "alloc_scan", "k_integrate": "integrate", "k_raycast": "raycast"}
 kern = {}
