@@ -131,6 +131,7 @@ struct se_hip_pipeline {
   unsigned short* tile_cost = nullptr;   // raycast scheduling hint: per wave tile, cost in the previous launch (see RayArgs)
   int* prio_thr = nullptr;               // its three priority thresholds (device; written by the integration sweep)
   bool prio_hint = true;                 // SE_HIP_PRIO=0 switches the hint off
+  int prio_permille[3] = {400, 150, 50}; // share of the tiles raised to priority >= 1 / >= 2 / 3 (SE_HIP_PRIO_SHARE="a,b,c", per mille)
   int xcd_swizzle = 0; // raycast: supertile edge (in 8x8-pixel wave tiles) of the XCD-aware workgroup -> tile mapping; 0 = row-major
 #ifdef SE_DIAG
   uint32_t* diag_pix = nullptr;   // diagnostic build: per-pixel / per-wave raycast records (se_hip_diag_*)
@@ -457,6 +458,10 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
 #endif
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
+    int a = 0, b = 0, c = 0;
+    if (std::sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3 && a >= b && b >= c && c >= 0 && a <= 1000) { p->prio_permille[0] = a; p->prio_permille[1] = b; p->prio_permille[2] = c; }
+  }
   p->max_level = ilog2(N);
   p->leaf_level = p->max_level - 3;
   DevMap& m = p->map;
@@ -707,11 +712,16 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   a.depth_fine = s2d(voxelsize); a.depth_mid = s2d(10.f * voxelsize); a.depth_coarse = s2d(30.f * voxelsize);
   // Overlap mode: the scan runs on the side stream as soon as the previous sweep is done, i.e.
   // concurrently with the previous frame's raycast, and defers its occ[] updates (join_scan).
-  const bool ov = p->overlap;
+  // ... unless there is nothing to overlap with: a caller that synchronises every frame (a SLAM loop whose next pose
+  // depends on this frame's raycast) finds the main stream idle here, and the scan then goes straight onto it -- no
+  // cross-stream events between scan and sweep (closed loop 110 -> 9x us per frame).  Row-sharded replicas keep the scan
+  // stream: their all-gather is ordered on it.
+  const bool ov = p->overlap && (p->sharded || hipStreamQuery(p->stream) == hipErrorNotReady);
   hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
   ms.defer_occ = ov ? 1 : 0;
   if (ov) HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0));
+  else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here
   HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), s));
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
   const dim3 grid((npix + SE_WG_SCAN - 1) / SE_WG_SCAN), block(SE_WG_SCAN);
@@ -861,6 +871,7 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   a.ctr_mirror = p->ctr_host;   // the kernel refreshes the host copy of the counters (next frame's launch geometry)
   if (p->prio_hint) {
     a.tile_cost = p->tile_cost; a.prio_thr = p->prio_thr;
+    for (int i = 0; i < 3; ++i) a.prio_permille[i] = p->prio_permille[i];
     a.n_tiles = ((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H);
   }
   const dim3 block(SE_WG);

@@ -425,20 +425,21 @@ struct IntegArgs {
 #endif
   uint32_t* ctr_mirror;    // pinned host copy of ctr[] (launch-geometry estimate of the next sweep), may be null
   // raycast scheduling hint (see RayArgs::tile_cost): this launch also turns the previous raycast's per-tile costs into
-  // the three priority thresholds of the next one (top 20 % / 7 % / 2.5 % of the tiles); null = hint off
+  // the three priority thresholds of the next one (top 40 % / 15 % / 5 % of the tiles by default); null = hint off
   const unsigned short* tile_cost;
   int n_tiles;
   int* prio_thr;
+  int prio_permille[3];    // share of the tiles (per mille) that get priority >= 1 / >= 2 / 3
 };
 
 // One workgroup: 256-bin histogram of the tile costs, thresholds = smallest cost v with #(cost >= v) <= fraction * n.
-__device__ __forceinline__ void se_prio_thresholds(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist) {
+__device__ __forceinline__ void se_prio_thresholds(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist, const int* permille) {
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[min((int)cost[i], 255)], 1u);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned lim[3] = {(unsigned)n / 5u, (unsigned)(n * 7) / 100u, (unsigned)n / 40u};
+    const unsigned lim[3] = {(unsigned)((long long)n * permille[0] / 1000), (unsigned)((long long)n * permille[1] / 1000), (unsigned)((long long)n * permille[2] / 1000)};
     int t[3] = {256, 256, 256};
     unsigned acc = 0u;
     for (int v = 255; v >= 1; --v) {
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
   if (a.commit_occ) se_occ_commit(m, a.occ_lists);   // nothing in this kernel reads occ[]; the raycast that follows does
   __shared__ unsigned s_hist[256];
-  if (a.prio_thr && blockIdx.x == 0) se_prio_thresholds(a.tile_cost, a.n_tiles, a.prio_thr, s_hist);
+  if (a.prio_thr && blockIdx.x == 0) se_prio_thresholds(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille);
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
