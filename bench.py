@@ -272,7 +272,8 @@ def pmc_traffic(kernel: str, args):
         except Exception:
             continue
         w = d.get("workload", {})
-        if (w.get("width"), w.get("height"), w.get("res"), w.get("field")) == (args.width, args.height, args.res, args.field):
+        if (w.get("width"), w.get("height"), w.get("res"), w.get("field")) == (args.width, args.height, args.res, args.field) and \
+                abs(w.get("mu", args.mu) - args.mu) < 1e-9:
             if kernel in d.get("kernels", {}):
                 best = (d["kernels"][kernel]["traffic_bytes"], os.path.basename(path))
     return best

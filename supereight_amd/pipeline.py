@@ -87,6 +87,8 @@ def load_library(rebuild: bool = True):
         path = _build.LIB
         alt = os.environ.get("SE_HIP_LIB")   # A/B of kernel variants built to another path (tools/)
         if alt:
+            import sys
+            print(f"supereight_amd: SE_HIP_LIB is set -- loading {alt} instead of the in-tree libse_hip.so (A/B tooling)", file=sys.stderr)
             path, rebuild = alt, False
         if rebuild:
             try:

@@ -105,6 +105,6 @@ for k in fetch:
             kern[nice] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k],
                           "traffic_bytes": (2.0 * fetch[k] + write[k]) * 1024.0}
 wl = {"width": int(os.environ.get("SE_PROF_W", 640)), "height": int(os.environ.get("SE_PROF_H", 480)),
-      "res": int(os.environ.get("SE_PROF_RES", 512)), "field": os.environ.get("SE_PROF_FIELD", "sdf")}
+      "res": int(os.environ.get("SE_PROF_RES", 512)), "field": os.environ.get("SE_PROF_FIELD", "sdf"), "mu": float(os.environ.get("SE_PROF_MU", 0.1))}
 with open(os.path.join(out_dir, "pmc_traffic.json"), "w") as fh:
     json.dump({"workload": wl, "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE) KB", "kernels": kern}, fh, indent=1)
