@@ -336,7 +336,7 @@ def main():
         sp.frame(depth_ptrs[f], poses[f], k, mu, f)
     torch.cuda.synchronize()
     sp.p.counts()  # raises if a pool or key list overflowed during warm-up
-    stride = max(1, args.event_stride)
+    stride = max(1, min(args.event_stride, K // 10 if K >= 10 else 1))   # at least ~10 sampled frames inside the K contract steps
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -358,9 +358,8 @@ def main():
     sustained = None
     if extra:
         t2 = time.perf_counter()
+        sp.p.enable_timing(False)                   # kernel events (and the roofline) belong to the K contract steps
         for f in range(warm + K, F):
-            if not args.no_events:
-                sp.p.enable_timing((f - warm) % stride == 0)
             sp.frame(depth_ptrs[f], poses[f], k, mu, f)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
@@ -402,8 +401,8 @@ def main():
         rows = (0, H)
         rp = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=local_rank)
         rp.enable_stats(True)
-        # instrumented replay of the same frames: exact work counts of the timed launches
-        for f in range(F):
+        # instrumented replay of the same frames: exact work counts of the K timed launches
+        for f in range(warm + K):
             rp.set_depth_device(depth_ptrs[f])
             rp.setPose(poses[f])
             if f == warm:
@@ -412,7 +411,7 @@ def main():
             rp.raycasting(k, mu, f)
         st = rp.stats()
         rp.close()
-        abytes = algorithmic_bytes(st, F - warm, W, H, 8 if field == SDF else 16)
+        abytes = algorithmic_bytes(st, K, W, H, 8 if field == SDF else 16)
         device_voxel_bytes = 8   # what the HIP path stores per voxel for BOTH field types (x, y float planes); OFusion's reference layout is 16 B
         per_kernel = {}
         for kk, v in timings.items():
@@ -436,9 +435,9 @@ def main():
             result["roofline"]["traffic"] = tr[0]
             result["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr[1]
         result["kernels"] = per_kernel
-        result["work_per_frame"] = {kk: st[kk] / (F - warm) for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
+        result["work_per_frame"] = {kk: st[kk] / K for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
         if field != SDF:   # the reference-layout figure flatters OFusion: say what the device really moves
-            dbytes = algorithmic_bytes(st, F - warm, W, H, device_voxel_bytes)
+            dbytes = algorithmic_bytes(st, K, W, H, device_voxel_bytes)
             result["roofline"]["device_layout_bytes_per_launch"] = dbytes[dom]
             result["roofline"]["device_layout_frac"] = dbytes[dom] / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
 

@@ -132,3 +132,44 @@ def test_sharded_pipeline_stream_plan_single_rank_rccl(exchange, monkeypatch):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_create_replicas_partitions_the_image_rows():
+    """se_hip_create_replicas (the device_ids[] form of the constructor): one row-sharded replica per listed
+    device, shares aligned to the 8-row raycast tiles -- here the same device three times.  Together the replicas
+    raycast the whole image: their tiles stitched = the unsharded pipeline's."""
+    import ctypes as C
+    from supereight_amd.pipeline import _Config, load_library
+    lib = load_library()
+    W, H, N, dim, mu = 160, 116, 256, 2.4, 0.1
+    cfg = _Config(W, H, N, dim, SDF, 0, 0, 0, 0)
+    ids = (C.c_int32 * 3)(0, 0, 0)
+    handles = (C.c_void_p * 3)()
+    assert lib.se_hip_create_replicas(C.byref(cfg), ids, 3, handles) == 0
+    parts = row_partition(H, 3)
+    stream = SyntheticStream(W, H, dim)
+    reps = []
+    for r in range(3):
+        p = DenseSLAMPipeline.__new__(DenseSLAMPipeline)          # adopt the handle the C call made
+        p.lib, p.W, p.H, p.size, p.dim, p.field, p._h, p._keepalive = lib, W, H, N, dim, SDF, C.c_void_p(handles[r]), None
+        p.pose_ = np.eye(4, dtype=np.float32)
+        reps.append(p)
+    for f in range(4):
+        depth, pose = stream.depth(f), stream.pose(f)
+        for p in reps:
+            p.set_depth(depth); p.setPose(pose)
+            p.integration(stream.k, 1, mu, f)      # (each replica only allocates what its own rows see: the exchange is the caller's)
+            p.raycasting(stream.k, mu, f)
+    assert parts[0][0] == 0 and parts[-1][1] == H and all(parts[i][1] == parts[i + 1][0] for i in range(2))
+    for r, p in enumerate(reps):
+        b, e = parts[r]
+        assert (b % 8 == 0) and (e % 8 == 0 or e == H)
+        v, n = p.vertex_normal()
+        touched = (n != 0).any(axis=-1)            # raycastKernel writes a unit normal or (INVALID, 0, 0) to every pixel it owns
+        assert touched[b:e].all() and not touched[:b].any() and not touched[e:].any()
+    # more devices than tiles is refused, and nothing leaks
+    ids20 = (C.c_int32 * 20)(*([0] * 20))
+    h20 = (C.c_void_p * 20)()
+    assert lib.se_hip_create_replicas(C.byref(cfg), ids20, 20, h20) < 0 and all(not h for h in h20)
+    for p in reps:
+        p.close()
