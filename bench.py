@@ -216,7 +216,10 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
       pooled       the headline's pipelined loop on pooled bricks (max_blocks set: bump-allocated bricks behind the
                    index instead of one brick slot per grid cell)."""
     from supereight_amd.pipeline import DenseSLAMPipeline
+    from supereight_amd.synthetic import to_colmajor
     W, H, N, dim, mu = args.width, args.height, args.res, args.dim, args.mu
+    poses_cm = [to_colmajor(q) for q in poses]
+    k32 = np.ascontiguousarray(k, dtype=np.float32).reshape(4)
     out = {}
 
     def run(label, per_frame_sync, track, **kw):
@@ -228,13 +231,16 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
             if f == warm:
                 p.sync()
                 t0 = time.perf_counter()
-            p.set_depth_device(depth_ptrs[f])
-            if track and f > 3:
-                tracked += int(p.tracking(k, 1e-5, 1, f))
+            if track:
+                p.set_depth_device(depth_ptrs[f])
+                if f > 3:
+                    tracked += int(p.tracking(k, 1e-5, 1, f))
+                else:
+                    p.setPose(poses[f])
+                p.integration(k, 1, mu, f)
+                p.raycasting(k, mu, f)
             else:
-                p.setPose(poses[f])
-            p.integration(k, 1, mu, f)
-            p.raycasting(k, mu, f)
+                p.frame(depth_ptrs[f], poses_cm[f], k32, mu, f)     # set_depth_device + integration + raycasting in one FFI call
             if per_frame_sync:
                 p.sync()
         p.sync()
@@ -319,8 +325,10 @@ def main():
     # ---- inputs: the whole stream resident in HBM before anything is timed
     stream, stream_name = make_stream(args, F)
     host_depth = np.stack([stream.depth(f) for f in range(F)])
+    from supereight_amd.synthetic import to_colmajor
     poses = [stream.pose(f) for f in range(F)]
-    k = stream.k
+    poses_cm = [to_colmajor(q) for q in poses]      # the C-ABI layout, converted outside the timed region
+    k = np.ascontiguousarray(stream.k, dtype=np.float32).reshape(4)
     dev = torch.device("cuda", local_rank)
     depth = torch.from_numpy(host_depth).to(dev)
     depth_ptrs = [depth[f].data_ptr() for f in range(F)]
@@ -333,10 +341,12 @@ def main():
             dist.barrier()
 
     for f in range(warm):
-        sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+        sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
     torch.cuda.synchronize()
     sp.p.counts()  # raises if a pool or key list overflowed during warm-up
-    stride = max(1, min(args.event_stride, K // 10 if K >= 10 else 1))   # at least ~10 sampled frames inside the K contract steps
+    # per-kernel HIP events on every stride-th contract step: each sampled frame costs 6 event records on the launch
+    # streams (measured: every 2nd frame sampled lowers `value` by 9 %, every 5th by < 2 %), so at least 4 samples, not more
+    stride = max(1, min(args.event_stride, K // 4 if K >= 4 else 1))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -344,7 +354,7 @@ def main():
     for f in range(warm, warm + K):
         if not args.no_events:
             sp.p.enable_timing((f - warm) % stride == 0)   # sampled: HIP events on the launch stream
-        sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+        sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
         if throttle and (f - warm) % throttle == throttle - 1:
             sp.p.sync()
     torch.cuda.synchronize()
@@ -360,7 +370,7 @@ def main():
         t2 = time.perf_counter()
         sp.p.enable_timing(False)                   # kernel events (and the roofline) belong to the K contract steps
         for f in range(warm + K, F):
-            sp.frame(depth_ptrs[f], poses[f], k, mu, f)
+            sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         sustained = {"frames": K + extra, "fps": (K + extra) / (elapsed + (t3 - t2)), "fps_second_region": extra / (t3 - t2),

@@ -127,6 +127,12 @@ int se_hip_alloc_exchange(se_hip_pipeline* p, uint64_t* recv_device, int64_t wor
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate,
                            float mu, uint32_t frame);
 
+/* One frame of the loop of se_apps/src/benchmark.cpp:148-167 in one call: hand-over of a device-resident float_depth_
+ * (NULL = keep the current depth image), then integration(), then raycasting() with the same pose -- exactly
+ * se_hip_set_depth_device + se_hip_integrate + se_hip_raycast.  Returns bit 0 = integration ran, bit 1 = raycasting ran. */
+int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t integration_rate,
+                 float mu, uint32_t frame);
+
 /* ---- bool DenseSLAMSystem::raycasting(const Vector4f& k, float mu, unsigned frame)
  *      (DenseSLAMSystem.h:212, DenseSLAMSystem.cpp:191-204) -> vertex_, normal_ */
 int se_hip_raycast(se_hip_pipeline* p, const float pose[16], const float k[4], float mu, uint32_t frame);

@@ -377,6 +377,8 @@ int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
 
 int check(se_hip_pipeline* p) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == p->device) return SE_HIP_OK;
   hipError_t e = hipSetDevice(p->device);
   if (e != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
   return SE_HIP_OK;
@@ -900,6 +902,21 @@ int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4],
   int r = se_hip_alloc_scan(p, pose, k, rate, mu, frame);
   if (r <= 0) return r;
   return se_hip_integrate_sweep(p, pose, k, rate, mu, frame);
+}
+
+// One frame of the hot path in one call: float_depth_ hand-over (device pointer) + integration() + raycasting().
+// The same three calls a host makes per frame, without crossing the FFI three times (ctypes: ~5 us each).
+int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  if (int r = check(p)) return r;
+  if (device_depth_m) p->depth = device_depth_m;
+  int ran = 0;
+  int r = se_hip_integrate(p, pose, k, rate, mu, frame);
+  if (r < 0) return r;
+  ran |= r > 0 ? 1 : 0;
+  r = se_hip_raycast(p, pose, k, mu, frame);
+  if (r < 0) return r;
+  ran |= r > 0 ? 2 : 0;
+  return ran;   // bit 0: integration ran, bit 1: raycasting ran
 }
 
 // ------------------------------------------------------------------------------------ raycast

@@ -143,6 +143,15 @@ class ShardedPipeline:
 
     def frame(self, depth_ptr: int, pose, k, mu: float, frame: int, integration_rate: int = 1):
         p = self.p
+        if not self.exchange and getattr(pose, "shape", None) == (16,):
+            # single replica, pose already in the C-ABI layout (to_colmajor): the whole frame is one FFI call
+            words = self.big_words if frame <= BIG_FRAMES else self.small_words
+            if words != self._words:
+                p.set_new_keys_buffer(self.send.data_ptr(), words, keepalive=self.send)
+                self._words = words
+            return p.frame(depth_ptr, pose, k, mu, frame, integration_rate) & 1
+        if getattr(pose, "shape", None) == (16,):
+            pose = np.asarray(pose, np.float32).reshape(4, 4).T
         p.set_depth_device(depth_ptr)
         p.setPose(pose)
         words = self.big_words if frame <= BIG_FRAMES else self.small_words

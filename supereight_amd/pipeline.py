@@ -55,6 +55,7 @@ EXPORTS = {
     "se_hip_alloc_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
+    "se_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "se_hip_track": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int32, _f32p]),
@@ -197,6 +198,11 @@ class DenseSLAMPipeline:
     def integration(self, k, integration_rate: int, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_integrate(self._h, self._pose_cm, self._k(k),
                                                           integration_rate, mu, frame)))
+
+    def frame(self, depth_ptr: int, pose_cm, k, mu: float, frame: int, integration_rate: int = 1) -> int:
+        """One frame in one FFI call: device depth pointer + integration() + raycasting().  pose_cm = the camera->world pose as
+        16 float32 in column-major order (to_colmajor(pose)); returns bit 0 = integrated, bit 1 = raycast."""
+        return self._check(self.lib.se_hip_frame(self._h, C.c_void_p(depth_ptr), pose_cm, self._k(k), integration_rate, mu, frame))
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm, self._k(k), mu, frame)))
