@@ -186,7 +186,7 @@ def cpu_baseline(args, n_timed: int):
 
 def prewarm(args, field, depth_ptrs, poses, k, device, ms: float = 90.0):
     """Untimed: keeps the GPU busy with the same kernels on a scratch map for `ms` milliseconds right before a timed
-    region.  An MI355X that has been idle sits in a low-power state; measured on the bench box (tools/long_run.py), the first
+    region (the pipeline to be timed already exists by then).  An MI355X that has been idle sits in a low-power state; measured on the bench box (tools/long_run.py), the first
     ~20 ms of sustained load end in ONE stall of 35-40 ms while the clocks come up (frames run 78-81 us before it and
     75-76 us ever after, 3000 frames checked).  A 1.6 ms timed region either dodges it or, 200 frames long, eats it whole;
     with the ramp behind us the K timed steps measure the steady state."""
@@ -202,8 +202,7 @@ def prewarm(args, field, depth_ptrs, poses, k, device, ms: float = 90.0):
             p.integration(k, 1, args.mu, f); p.raycasting(k, args.mu, f)
             f += 1
         p.sync()
-    p.close()
-    return f
+    return f, p      # the caller closes the scratch pipeline AFTER its timed region: freeing 2 GiB now would idle the GPU again
 
 
 def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
@@ -223,8 +222,8 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
     out = {}
 
     def run(label, per_frame_sync, track, **kw):
-        prewarm(args, field, depth_ptrs, poses, k, device)
         p = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=device, **kw)
+        _, scratch = prewarm(args, field, depth_ptrs, poses, k, device)
         tracked = 0
         t0 = None
         for f in range(warm + n):
@@ -254,6 +253,7 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
                             "pins GPU == oracle); the leg measures the loop's speed, not the tracker's accuracy")
         p.counts()   # raises on pool / key-list overflow
         p.close()
+        scratch.close()
         out[label] = rec
 
     run("closed_loop", True, False)
@@ -333,8 +333,10 @@ def main():
     depth = torch.from_numpy(host_depth).to(dev)
     depth_ptrs = [depth[f].data_ptr() for f in range(F)]
 
-    prewarm_frames = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else 0
+    # the pipeline is created BEFORE the pre-warm and the scratch map is freed AFTER the timed regions: allocating or
+    # freeing gigabytes idles the GPU for tens of milliseconds, long enough for the clocks to drop again
     sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank)
+    prewarm_frames, scratch = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else (0, None)
 
     def barrier():
         if world > 1:
@@ -379,6 +381,8 @@ def main():
     sp.p.enable_timing(False)
     nblocks, nnodes = sp.p.counts()
     sp.close()
+    if scratch is not None:
+        scratch.close()
 
     result = None
     if rank == 0:
