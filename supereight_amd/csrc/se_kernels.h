@@ -978,9 +978,12 @@ struct RaySpan { float tcmin, tmax; int trips; };
 //  * advance: subtracting scale_exp2 flips exactly bit `scale` unless it borrows, so old ^ new of the
 //    three coordinates is the reference's differing_bits, and "leaves the parent" (idx & step_mask) is
 //    "some bit above `scale` changed".
-template <bool SHALLOW>   // SHALLOW: the caller guarantees a.has_deep == 0 (every non-leaf level is staged in LDS)
+struct SeNoHook { __device__ __forceinline__ void operator()() const {} };
+// `before_loop` runs between the ray set-up and the traversal loop (the raycast kernel finishes the LDS staging of the
+// occupancy bits there, so that the staging loads fly under the set-up arithmetic); `live` = false skips the loop.
+template <bool SHALLOW, typename Hook = SeNoHook>   // SHALLOW: the caller guarantees a.has_deep == 0 (every non-leaf level is staged in LDS)
 __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs& a, f3 origin, f3 direction,
-                                                 const uint32_t* s_occ, uint32_t* s_par, float* s_tmax) {
+                                                 const uint32_t* s_occ, uint32_t* s_par, float* s_tmax, Hook before_loop = Hook(), bool live = true) {
   const int tid = threadIdx.x;
   f3 pos = {1.0f, 1.0f, 1.0f};
   uint32_t parent = 1u;  // root
@@ -1022,7 +1025,8 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   // both updates are computed for every lane and selected (straight-line code, no exec-mask juggling);
   // only the rare events are branches: leaving a parent (stack read), entering a leaf parent (sibling
   // byte load) and the global occupancy word of volumes > 512^3.
-  const int max_trips = (SE_DBG_PHASES(a) & 4) ? 0 : 4096;
+  before_loop();
+  const int max_trips = ((SE_DBG_PHASES(a) & 4) || !live) ? 0 : 4096;
   const bool has_deep = SHALLOW ? false : (a.has_deep != 0);
   int guard = 0;
   // The occupancy word of a trip depends only on (parent, pos, scale), which are final at the end of the previous
@@ -1322,9 +1326,13 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
 #ifdef SE_DIAG
   const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
 #endif
-  for (int i = threadIdx.x; i < a.cache_words; i += SE_WG_RAY) s_occ[i] = m.occ[i];   // (a per-level copy of only the used words was slower)
-  __syncthreads();
-  const unsigned long long tk1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+  // LDS staging of the occupancy words, split in two: the global loads are issued here, the LDS writes and the barrier
+  // follow the ray set-up inside se_first_leaf (a per-level copy of only the used words was slower)
+  constexpr int kStage = 2048 / SE_WG_RAY;      // occupancy levels <= 5 are 2048 words
+  uint32_t st[kStage];
+#pragma unroll
+  for (int j = 0; j < kStage; ++j) { const int i = threadIdx.x + j * SE_WG_RAY; st[j] = i < a.cache_words ? m.occ[i] : 0u; }
+  unsigned long long tk1 = tk0;
   unsigned long long tk2 = tk1, tk3 = tk1;
   const FieldConst fc = se_field_const(m);
   const int lane = threadIdx.x & 63;
@@ -1363,10 +1371,19 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
 #ifdef SE_DIAG
   unsigned d_trips = 0, d_batches = 0;
 #endif
-  if (px < a.W && py < a.row_end) {
-    const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
-    const f3 org = {a.org[0], a.org[1], a.org[2]};
-    const RaySpan span = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax);
+  const bool in_image = px < a.W && py < a.row_end;
+  const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
+  const f3 org = {a.org[0], a.org[1], a.org[2]};
+  auto finish_staging = [&]() {
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) { const int i = threadIdx.x + j * SE_WG_RAY; if (i < a.cache_words) s_occ[i] = st[j]; }
+    for (int i = threadIdx.x + kStage * SE_WG_RAY; i < a.cache_words; i += SE_WG_RAY) s_occ[i] = m.occ[i];   // (SE_HIP_RAY_CACHE_LEVELS > 5)
+    __syncthreads();
+    if (STATS) tk1 = __builtin_amdgcn_s_memtime();
+  };
+  // every thread of the workgroup goes through the set-up and the barrier; only rays inside the image enter the loop
+  const RaySpan span = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax, finish_staging, in_image);
+  if (in_image) {
     const float t_min = span.tcmin, tfar = span.tmax;
     if (STATS) tk2 = __builtin_amdgcn_s_memtime();
     float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
