@@ -118,8 +118,11 @@ struct se_hip_pipeline {
   float* bspline = nullptr;
   float* logodds = nullptr;
   unsigned long long* chain = nullptr;  // 3 candidates for the keys[0] quirk
-  unsigned long long* newkeys_own = nullptr;
+  unsigned long long* newkeys_own = nullptr;    // the handle's own key lists: two, used alternately by successive scans; the sweep
+  unsigned long long* newkeys_own2 = nullptr;   // kernel of a frame clears the count word of the list the next scan will use
   unsigned long long cap_keys_own = 0;
+  int own_next = 0;                             // which own list the next scan appends to
+  bool own_clean[2] = {false, false};           // its count word is known to be zero (cleared by a sweep or a memset, not used since)
   uint32_t* ctr_host = nullptr;         // pinned
   bool timing = false, stats = false;
   std::vector<TimedLaunch> pending;
@@ -410,6 +413,9 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemsetAsync(m.nlevel, 0, p->cap_nodes, p->stream);
   hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
   hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), p->stream);
+  if (p->newkeys_own) hipMemsetAsync(p->newkeys_own, 0, sizeof(unsigned long long), p->stream);
+  if (p->newkeys_own2) hipMemsetAsync(p->newkeys_own2, 0, sizeof(unsigned long long), p->stream);
+  p->own_clean[0] = p->newkeys_own != nullptr; p->own_clean[1] = p->newkeys_own2 != nullptr;
   // node 0 = root: level 0, side = size
   const uint32_t ctr0[C_COUNT] = {0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u};
   hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
@@ -523,6 +529,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(m.stats, S_COUNT * sizeof(unsigned long long));
   ALLOC(m.newkeys, (m.cap_keys + 1) * sizeof(unsigned long long));
   p->newkeys_own = m.newkeys; p->cap_keys_own = m.cap_keys;
+  ALLOC(p->newkeys_own2, (m.cap_keys + 1) * sizeof(unsigned long long));
   ALLOC(p->depth_own, (size_t)cfg->width * cfg->height * sizeof(float));
   ALLOC(p->vertex, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   ALLOC(p->normal, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
@@ -566,7 +573,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own,
+  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
@@ -724,7 +731,18 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   ms.defer_occ = ov ? 1 : 0;
   if (ov) HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0));
   else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here
-  HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), s));
+  const bool own_list = p->map.newkeys == p->newkeys_own || p->map.newkeys == p->newkeys_own2;
+  if (own_list) {
+    // the own lists alternate; the previous frame's sweep kernel has already cleared this one's count word (no fill
+    // kernel in front of the scan: 5 us on the chain sweep -> scan -> next sweep that the scan stream adds to a frame)
+    const int w = p->own_next;
+    p->map.newkeys = w ? p->newkeys_own2 : p->newkeys_own;
+    ms.newkeys = p->map.newkeys;
+    if (!p->own_clean[w]) HIP_TRY(hipMemsetAsync(p->map.newkeys, 0, sizeof(unsigned long long), s));
+    p->own_clean[w] = false;
+  } else {
+    HIP_TRY(hipMemsetAsync(m.newkeys, 0, sizeof(unsigned long long), s));   // caller's buffer (multi-GPU send buffer)
+  }
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
   const dim3 grid((npix + SE_WG_SCAN - 1) / SE_WG_SCAN), block(SE_WG_SCAN);
   {
@@ -871,6 +889,12 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   a.W = p->cfg.width; a.H = p->cfg.height;
   a.bspline = p->bspline; a.logodds = p->logodds;
   a.ctr_mirror = p->ctr_host;   // the kernel refreshes the host copy of the counters (next frame's launch geometry)
+  if (p->map.newkeys == p->newkeys_own || p->map.newkeys == p->newkeys_own2) {
+    const int other = p->map.newkeys == p->newkeys_own ? 1 : 0;   // the list this frame's scan did NOT use: consumed a frame ago
+    a.zero_count = other ? p->newkeys_own2 : p->newkeys_own;
+    p->own_clean[other] = true;
+    p->own_next = other;
+  }
   if (p->prio_hint) {
     a.tile_cost = p->tile_cost; a.prio_thr = p->prio_thr;
     for (int i = 0; i < 3; ++i) a.prio_permille[i] = p->prio_permille[i];

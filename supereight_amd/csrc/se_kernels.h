@@ -424,6 +424,8 @@ struct IntegArgs {
   int debug;               // diagnostic build only: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
 #endif
   uint32_t* ctr_mirror;    // pinned host copy of ctr[] (launch-geometry estimate of the next sweep), may be null
+  unsigned long long* zero_count;   // count word of the key list the NEXT allocation scan appends to (the handle's two own lists
+                                    // alternate): cleared here, so that no fill kernel sits in front of that scan; may be null
   // raycast scheduling hint (see RayArgs::tile_cost): this launch also turns the previous raycast's per-tile costs into
   // the three priority thresholds of the next one (top 40 % / 15 % / 5 % of the tiles by default); null = hint off
   const unsigned short* tile_cost;
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   // counters as this sweep sees them -> pinned host memory (posted write; sizes the next sweep's grid
   // without a device-to-host copy between this kernel and the raycast)
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
+  if (a.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_count = 0ull;
   if (a.commit_occ) se_occ_commit(m, a.occ_lists);   // nothing in this kernel reads occ[]; the raycast that follows does
   __shared__ unsigned s_hist[256];
   if (a.prio_thr && blockIdx.x == 0) se_prio_thresholds(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille);

@@ -145,17 +145,14 @@ class ShardedPipeline:
         p = self.p
         if not self.exchange and getattr(pose, "shape", None) == (16,):
             # single replica, pose already in the C-ABI layout (to_colmajor): the whole frame is one FFI call
-            words = self.big_words if frame <= BIG_FRAMES else self.small_words
-            if words != self._words:
-                p.set_new_keys_buffer(self.send.data_ptr(), words, keepalive=self.send)
-                self._words = words
+            # (no exchange: the scan writes the handle's own key lists, whose count words the sweep kernel clears)
             return p.frame(depth_ptr, pose, k, mu, frame, integration_rate) & 1
         if getattr(pose, "shape", None) == (16,):
             pose = np.asarray(pose, np.float32).reshape(4, 4).T
         p.set_depth_device(depth_ptr)
         p.setPose(pose)
         words = self.big_words if frame <= BIG_FRAMES else self.small_words
-        if words != self._words:
+        if self.exchange and words != self._words:
             p.set_new_keys_buffer(self.send.data_ptr(), words, keepalive=self.send)
             self._words = words
         ran = p.alloc_scan(k, integration_rate, mu, frame)
