@@ -90,7 +90,8 @@ struct se_hip_pipeline {
   TrackData* track = nullptr;
   float* reduce_partial = nullptr;
   float* reduce_out = nullptr;       // 8 x 32
-  float* reduce_host = nullptr;      // pinned, 8 x 32
+  float* reduce_host = nullptr;      // pinned, 8 x 32 (+ 1 word: sequence number of the last reduction that landed)
+  unsigned reduce_seq = 0;
   int track_iterations = 0;
   unsigned char* rgbw = nullptr;   // render target (W*H*4)
   DevMap map{};
@@ -1020,7 +1021,8 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     HIP_TRY(hipMemsetAsync(p->track, 0, (size_t)W * H * sizeof(TrackData), s));
     HIP_TRY(hipMalloc((void**)&p->reduce_partial, 8 * SE_TRACK_SEGMENTS * 32 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&p->reduce_out, 8 * 32 * sizeof(float)));
-    HIP_TRY(hipHostMalloc((void**)&p->reduce_host, 8 * 32 * sizeof(float)));
+    HIP_TRY(hipHostMalloc((void**)&p->reduce_host, (8 * 32 + 16) * sizeof(float)));
+    std::memset(p->reduce_host, 0, (8 * 32 + 16) * sizeof(float));
   }
   // pyramid (DenseSLAMSystem.cpp:149-163): scaled_depth_[0] is the current depth image
   const float* d0 = p->depth;
@@ -1068,9 +1070,17 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) a.T[r * 4 + c] = pose.m[r][c];
       hipLaunchKernelGGL(k_track, dim3((w + 255) / 256, h), dim3(256), 0, s, p->track, p->pyr_vertex[level], p->pyr_normal[level], p->vertex, p->normal, a);
       hipLaunchKernelGGL(k_track_reduce, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->reduce_partial, p->track, W, w, h);
-      hipLaunchKernelGGL(k_track_reduce_final, dim3(1), dim3(32), 0, s, p->reduce_out, p->reduce_partial);
-      HIP_TRY(hipMemcpyAsync(p->reduce_host, p->reduce_out, 8 * 32 * sizeof(float), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+      volatile unsigned* seq_word = (volatile unsigned*)(p->reduce_host + 8 * 32);
+      const unsigned seq = ++p->reduce_seq;
+      hipLaunchKernelGGL(k_track_reduce_final, dim3(1), dim3(32), 0, s, p->reduce_out, p->reduce_partial, p->reduce_host, (unsigned*)seq_word, seq);
+      HIP_TRY(hipGetLastError());
+      {   // wait for the sums to land in pinned memory (bounded: fall back to a stream synchronisation after ~50 ms)
+        unsigned long long spins = 0;
+        while (*seq_word != seq) {
+          if (++spins > 50000000ull) { HIP_TRY(hipStreamSynchronize(s)); if (*seq_word != seq) return fail(SE_HIP_E_DEVICE, "tracking reduction did not complete"); break; }
+          __builtin_ia32_pause();
+        }
+      }
       ++done;
       float x[6];
       solve6(p->reduce_host + 1, x);

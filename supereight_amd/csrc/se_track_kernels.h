@@ -173,17 +173,28 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_track_reduce(float* __restri
   }
   if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = lanes[0][t];
 }
-__global__ void k_track_reduce_final(float* __restrict__ out /*8*32*/, const float* __restrict__ partial) {
+// The sums also go straight to pinned host memory, followed by a sequence word: updatePoseKernel's 6x6 solve runs on the
+// host once per ICP iteration, and polling that word costs a few microseconds where a device-to-host copy plus a stream
+// synchronisation cost ~10 (19 iterations per frame).
+__global__ void k_track_reduce_final(float* __restrict__ out /*8*32*/, const float* __restrict__ partial, float* host_out, unsigned* host_seq, unsigned seq) {
   const int i = threadIdx.x;
-  if (i >= 32) return;
-  float row0 = 0.f;
-  for (int b = 0; b < 8; ++b) {
-    float total = 0.f;
-    for (int g = 0; g < SE_TRACK_SEGMENTS; ++g) total += partial[(b * SE_TRACK_SEGMENTS + g) * 32 + i];
-    out[b * 32 + i] = total;
-    if (b == 0) row0 = total; else row0 += total;
+  if (i < 32) {
+    float row0 = 0.f;
+    float rows[8];
+    for (int b = 0; b < 8; ++b) {
+      float total = 0.f;
+      for (int g = 0; g < SE_TRACK_SEGMENTS; ++g) total += partial[(b * SE_TRACK_SEGMENTS + g) * 32 + i];
+      rows[b] = total;
+      if (b == 0) row0 = total; else row0 += total;
+    }
+    rows[0] = row0;
+    for (int b = 0; b < 8; ++b) { out[b * 32 + i] = rows[b]; if (host_out) host_out[b * 32 + i] = rows[b]; }
   }
-  out[i] = row0;
+  if (host_seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) { *(volatile unsigned*)host_seq = seq; }
+  }
 }
 
 // renderTrackKernel (rendering.cpp:154-213)
