@@ -71,6 +71,13 @@ struct se_hip_pipeline {
   bool own_side = false;       // false after se_hip_set_scan_stream handed one in
   hipEvent_t ev_sweep = nullptr, ev_scan = nullptr;
   bool overlap = false;
+  // host gate (see RayArgs::gate): replaces the event between the sweep and the next frame's scan for unsharded replicas
+  bool host_gate = false;
+  uint32_t* gate_host = nullptr;   // pinned word the raycast kernel writes its sequence number to
+  uint32_t ray_seq = 0;            // raycast launches so far
+  uint32_t gate_target = 0;        // sequence number of the first raycast behind the last sweep
+  bool gate_armed = false;         // a sweep was enqueued that no scan / upload has waited for yet
+  bool gate_followed = false;      // ... and a raycast was enqueued behind it
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool upload_on_side = false; // the current depth image was uploaded on `side`
@@ -345,11 +352,29 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   return L;
 }
 
+// Host gate: returns once the last integration sweep has completed -- known from the sequence word the raycast kernel
+// behind it wrote when it started (no raycast behind it: the frames before the first raycast, integration-only
+// callers -> a stream synchronisation).
+void wait_last_sweep(se_hip_pipeline* p) {
+  if (!p->gate_armed) return;
+  p->gate_armed = false;
+  if (p->gate_followed) {
+    volatile uint32_t* w = p->gate_host;
+    for (unsigned long long spins = 0; (int32_t)(*w - p->gate_target) < 0; ++spins) {
+      if (spins > 400000000ull) { hipStreamSynchronize(p->stream); return; }   // (seconds: something is very slow; be safe)
+      __builtin_ia32_pause();
+    }
+    return;
+  }
+  hipStreamSynchronize(p->stream);
+}
+
 // Overlap mode: depth uploads go to the side stream, behind the previous sweep (the last reader of
 // the depth buffer) and in front of the scan that consumes them.
 hipStream_t upload_stream(se_hip_pipeline* p) {
   if (!p->overlap) return p->stream;
-  hipStreamWaitEvent(p->side, p->ev_sweep, 0);
+  if (p->host_gate) wait_last_sweep(p);
+  else hipStreamWaitEvent(p->side, p->ev_sweep, 0);
   return p->side;
 }
 
@@ -515,6 +540,13 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   hipEventCreateWithFlags(&p->ev_scan, hipEventDisableTiming | hipEventDisableSystemFence);
   p->sharded = (p->row_begin != 0 || p->row_end != cfg->height);
   p->overlap = dense && !std::getenv("SE_HIP_NO_OVERLAP");
+  p->host_gate = p->overlap && !p->sharded;
+  if (const char* ev = std::getenv("SE_HIP_HOST_GATE")) p->host_gate = p->host_gate && std::atoi(ev) != 0;   // tuning knob
+  if (p->host_gate) {
+    e = hipHostMalloc((void**)&p->gate_host, 64);
+    if (e != hipSuccess) return bail(e, "hipHostMalloc");
+    std::memset(p->gate_host, 0, 64);
+  }
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
   ALLOC(m.lbits, ((cells + 31) / 32) * sizeof(uint32_t));
@@ -586,6 +618,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   if (p->reduce_out) hipFree(p->reduce_out);
   if (p->reduce_host) hipHostFree(p->reduce_host);
   if (p->ctr_host) hipHostFree(p->ctr_host);
+  if (p->gate_host) hipHostFree(p->gate_host);
   if (p->mesh_ctr) hipFree(p->mesh_ctr);
   for (int i = 0; i < se_hip_pipeline::kStage; ++i) { if (p->stage_host[i]) hipHostFree(p->stage_host[i]); if (p->stage_done[i]) hipEventDestroy(p->stage_done[i]); }
   if (p->own_side && p->side) hipStreamDestroy(p->side);
@@ -600,12 +633,14 @@ int se_hip_sync(se_hip_pipeline* p) {
   if (int r = check(p)) return r;
   if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  p->gate_armed = false;   // every sweep enqueued so far is done
   return check_overflow(p);
 }
 
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
   if (int r = check(p)) return r;
   HIP_TRY(hipStreamSynchronize(p->stream));
+  p->gate_armed = false;
   drain_timings(p);
   if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
   p->stream = (hipStream_t)hip_stream;
@@ -730,7 +765,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
   ms.defer_occ = ov ? 1 : 0;
-  if (ov) HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0));
+  if (ov) { if (p->host_gate) wait_last_sweep(p); else HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0)); }
   else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here
   const bool own_list = p->map.newkeys == p->newkeys_own || p->map.newkeys == p->newkeys_own2;
   if (own_list) {
@@ -918,7 +953,10 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
       else hipLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, p->stream, m, p->depth, a);
     }
   }
-  hipEventRecord(p->ev_sweep, p->stream);   // the next frame's scan / depth upload may start behind this point
+  // the next frame's scan / depth upload may start behind this point: an event for the scan stream to wait on, or (host
+  // gate) the sequence number of the raycast that follows
+  if (p->host_gate) { p->gate_armed = true; p->gate_followed = false; p->gate_target = p->ray_seq + 1u; }
+  else hipEventRecord(p->ev_sweep, p->stream);
   HIP_TRY(hipGetLastError());
   return 1;
 }
@@ -953,7 +991,8 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (int r = join_scan(p)) return r;
   std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   const DevMap& m = p->map;
-  const RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
+  RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
+  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
   const RayArgs& a = L.a;
   const size_t smem = L.smem;
   const dim3 grid = L.grid, block(SE_WG_RAY);

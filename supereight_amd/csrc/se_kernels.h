@@ -711,6 +711,12 @@ struct RayArgs {
   // Scheduling hint (results do not depend on it): cost of every wave tile in the previous raycast launch,
   // trips + 5 * march batches of its slowest ray.  A launch ends when its slowest waves end, and those are known in
   // advance -- the silhouettes and depth edges of the previous frame -- so they start with a raised issue priority.
+  // Host gate: the first thread of the launch writes gate_seq to a pinned host word.  This launch starts only when the
+  // integration sweep in front of it on the same queue has completed, so a host that sees the word knows that sweep is
+  // done and may release the next frame's allocation scan on the other queue -- the dependency sweep(f) -> scan(f+1)
+  // without an event-record packet between sweep(f) and raycast(f) on this queue.
+  uint32_t* gate;
+  uint32_t gate_seq;
   unsigned short* tile_cost;
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_prio_thresholds)
 #ifdef SE_DIAG
@@ -1325,6 +1331,7 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   uint32_t* s_occ = smem;
   uint32_t* s_par = smem + a.cache_words;
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
+  if (a.gate && blockIdx.x == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef SE_DIAG
   const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
