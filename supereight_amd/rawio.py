@@ -113,3 +113,46 @@ class RawStream:
 
     def pose(self, frame: int) -> np.ndarray:
         return self.poses[frame]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ICL-NUIM scene directories -> .raw : the converter the reference ships as se_tools/scene2raw.cpp (its README's
+# data-set recipe, README.md:60-80).  ICL-NUIM `scene_00_NNNN.depth` files hold, per pixel and in row-major order, the
+# EUCLIDEAN distance along the ray in metres (text, whitespace separated); the .raw stream holds z-depth in uint16
+# millimetres.  Arithmetic as scene2raw.cpp:97-108: double precision, z = 1000 d / sqrt(((u-u0)/fx)^2 + ((v-v0)/fy)^2 + 1),
+# truncated to uint16 by the store (the camera constants are float there: scene2raw.cpp:25-38).
+ICL_SCENE_K = (np.float32(481.20), np.float32(-480.00), np.float32(319.50), np.float32(239.50))   # fx, fy, u0, v0 of the scene files
+
+
+def icl_ray_length_to_depth_mm(dist_m, k=ICL_SCENE_K) -> np.ndarray:
+    """(h, w) ray lengths in metres -> (h, w) uint16 z-depth in millimetres, as readDepthFile() stores them."""
+    d = np.asarray(dist_m, np.float64) * 1000.0
+    h, w = d.shape
+    fx, fy, u0, v0 = (np.float32(v) for v in k)
+    u = ((np.arange(w, dtype=np.float32) - u0) / fx).astype(np.float64)     # (u - _u0) / _focal_x is float arithmetic, stored in a double
+    v = ((np.arange(h, dtype=np.float32) - v0) / fy).astype(np.float64)
+    z = d / np.sqrt(u[None, :] * u[None, :] + v[:, None] * v[:, None] + 1.0)
+    return z.astype(np.int64).astype(np.uint16)          # double -> ushort: truncation, modulo 2^16 like the C cast on x86-64
+
+
+def read_icl_depth_file(path: str, width: int = 640, height: int = 480) -> np.ndarray:
+    vals = np.loadtxt(path, dtype=np.float64).reshape(-1)
+    if vals.size < width * height:
+        raise ValueError(f"{path}: {vals.size} values, {width * height} expected")
+    return vals[: width * height].reshape(height, width)   # (the reference also ignores one trailing value, scene2raw.cpp:91-92)
+
+
+def scene2raw(scene_dir: str, out_path: str, width: int = 640, height: int = 480) -> int:
+    """scene_00_0000.depth, scene_00_0001.depth, ... -> SLAMBench .raw (RGB planes zero: this path never reads them).
+    Returns the number of frames written."""
+    import os
+    frames = []
+    i = 0
+    while True:
+        f = os.path.join(scene_dir, f"scene_00_{i:04d}.depth")
+        if not os.path.exists(f):
+            break
+        frames.append(icl_ray_length_to_depth_mm(read_icl_depth_file(f, width, height)))
+        i += 1
+    write_raw(out_path, frames)
+    return i
