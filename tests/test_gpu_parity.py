@@ -97,3 +97,37 @@ def test_mm2meters_fused_upload():
         a.set_depth_mm(np.zeros((H + 1, W), np.uint16))   # "Invalid ratio."
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("field,W,H,N,dim,mu,frames", [(SDF, 320, 240, 512, 4.8, 0.1, 14), (OFUSION, 160, 120, 256, 2.4, 0.02, 10)], ids=["sdf", "ofusion"])
+def test_pipelined_stream_parity(field, W, H, N, dim, mu, frames):
+    """The parity cases above download the raycast after every frame, i.e. they synchronise, and a synchronised caller gets
+    the serial schedule (scan on the main stream).  Here the frames are enqueued back to back from device-resident depth
+    images, as bench.py does: the allocation scan of frame f+1 runs on the scan stream beside the raycast of frame f, released
+    by the host gate, the two key lists alternate, the occupancy bits are published by the sweep.  The final map and the
+    last raycast must still be the oracle's, bit for bit."""
+    import torch
+    from oracle.binding import OraclePipeline
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    from supereight_amd.synthetic import SyntheticStream, to_colmajor
+    s = SyntheticStream(W, H, dim)
+    depths = [s.depth(f) for f in range(frames)]
+    poses = [s.pose(f) for f in range(frames)]
+    dev = torch.from_numpy(np.stack(depths)).cuda()
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field)
+    assert gpu.scan_overlaps()
+    k = np.ascontiguousarray(s.k, np.float32)
+    for f in range(frames):
+        gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)       # no synchronisation between frames
+    cpu = OraclePipeline(field, N, dim, W, H)
+    for f in range(frames):
+        cpu.integrate(depths[f], poses[f], s.k, mu, f)
+        _, v_c, n_c = cpu.raycast(poses[f], s.k, mu, f)
+    m = compare_maps(cpu, gpu)
+    assert m["same_block_set"] and m["same_node_set"], m
+    assert m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0, m
+    assert m["node_x_mismatch"] == 0 and m["node_y_mismatch"] == 0, m
+    v_g, n_g = gpu.vertex_normal()
+    r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": v_g, "n_g": n_g}, dim / N)
+    assert r["hits_gpu"] > 1000 and r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, r
+    cpu.close(); gpu.close()
