@@ -8,8 +8,6 @@
 //   occ[]      occupancy bit pyramid: one bit per possible octant of every level, Morton order
 //              (the 8 children of an octant share one byte).  It is what the ray traversal walks;
 //              its top levels (37 KB for 512^3) are staged in LDS by the raycast kernel.
-//   lbits[]    one bit per cell of the block grid in linear (z, y, x) order: "this block is allocated".  The SDF march
-//              probes it to step over runs of unallocated blocks without touching their (cold) bricks.
 //   vx[], vy[] SoA voxel planes, 512 consecutive floats per block, voxel index x + 8y + 64z
 //              (se_core/include/se/node.hpp:139-144).  SDF: x = tsdf, y = weight.
 //              OFusion: x = log-odds, y = last-update time (the reference stores y as double;
@@ -40,7 +38,6 @@ struct DevMap {
   uint32_t* tab;
   uint32_t off[SE_MAX_LEVELS];
   uint32_t* occ;                  // occupancy bits in heap order: octant (level l, Morton index c) is bit (1 << 3l) | c
-  uint32_t* lbits;                // leaf bitmap in LINEAR order: bit block_linear(bx,by,bz) = block allocated (set at insertion, never deferred)
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)

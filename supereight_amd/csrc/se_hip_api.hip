@@ -432,7 +432,6 @@ void reset_map_state(se_hip_pipeline* p) {
   const size_t cells = (size_t)1 << (3 * p->leaf_level);
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.lbits, 0, ((cells + 31) / 32) * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
   hipMemsetAsync(m.npos, 0, p->cap_nodes * sizeof(uint32_t), p->stream);
@@ -549,7 +548,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   }
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
-  ALLOC(m.lbits, ((cells + 31) / 32) * sizeof(uint32_t));
   ALLOC(m.vx, slots * 512 * sizeof(float));
   ALLOC(m.vy, slots * 512 * sizeof(float));
   ALLOC(m.bpos, cap * sizeof(uint32_t));
@@ -606,7 +604,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
+  void* ptrs[] = {m.occ, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);

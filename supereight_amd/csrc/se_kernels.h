@@ -25,10 +25,6 @@
 #define SE_SPEC 2     // SDF march: samples fetched per memory round trip (measured 1 / 2 / 3 / 4: 51.3 / 50.3 / 50.0 / 51.6 us at 512^3, 81 / 77 / 78 / 82 us at 1024^3)
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
-#ifndef SE_RUN
-#define SE_RUN 0      // SDF march: blocks probed ahead in the leaf bitmap while the ray moves in largesteps (0 = off; 6 cuts the longest
-                      // march from 23 to 17 round trips but the launch got 9 us SLOWER at 512^3 -- measured r02, kept as an experiment)
-#endif
 
 // ------------------------------------------------------------------------------------------
 // index insertion (replaces Octree::allocate / allocate_level, se_core/include/se/octree.hpp:792-856)
@@ -63,8 +59,6 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
     const uint32_t slot = block_slot(m, idx, bp);
     m.bpos[idx] = bp;
     m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
-    const uint32_t lin = block_linear(m, x, y, z);
-    atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u));
     occ_set(m, level, x, y, z);
     atomicExch(e, slot + 1u);
   } else {
@@ -584,12 +578,6 @@ __device__ __forceinline__ void se_update_node_corner(const DevMap& m, const flo
 }
 
 // projective_functor::apply (projective_functor.hpp:139-160) in one launch.
-// Blocks: one wave per block, lane = x + 8*y, all 8 z-slices in flight: every slice is one
-// coalesced 256-byte row of each SoA plane and the 16 loads of a lane are issued before the first
-// use.  build_active_list's predicate (active || in_frustum) is evaluated per block at the top
-// (wave-uniform), update_block's visibility flag is a wave ballot.  Internal nodes (8 corner
-// values each) are swept by the same grid afterwards, one thread per corner.
-// projective_functor::apply (projective_functor.hpp:139-160) in one launch.
 // Blocks: one wave per block, lane = x + 8*y, 8 z-slices per lane: every slice is one coalesced
 // 256-byte row of each SoA plane and the 16 voxel loads of a lane are issued before the first use.
 // build_active_list's predicate (active || in_frustum) is evaluated per block at the top
@@ -597,7 +585,10 @@ __device__ __forceinline__ void se_update_node_corner(const DevMap& m, const flo
 // each) are swept by the same grid afterwards, one thread per corner.
 // Measured alternatives on MI355X (640x480 -> 512^3, ~10 k swept blocks, this version 29 us):
 // a 512-thread workgroup per block 41-49 us; software prefetch of the next block 32-44 us;
-// separate passes for projection / depth gathers / update 29 us (95 VGPRs instead of 59).
+// separate passes for projection / depth gathers / update 29 us (95 VGPRs instead of 59); 16-byte loads and stores
+// (lane = 4 consecutive x of the rows (y, z) and (y, z+4): the per-row projection twice per lane instead of 8 times,
+// 7 % fewer VALU instructions, 101 VGPRs instead of 91) 28.2 / 135.8 / 877 us against 27.7 / 130.6 / 852 us at
+// 512^3 / 1024^3 / 2048^3 -- the sweep is bound by neither instruction count nor load width.
 template <bool OFUSION, bool STATS>
 __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
   const int lane = threadIdx.x & 63;
@@ -1149,9 +1140,6 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
           // formed by the same float additions the sequential loop performs.
           float S = a.largestep;
           bool done = false;
-#if SE_RUN > 0
-          bool prev_full = false;   // the previous batch was consumed completely at step `largestep`
-#endif
           for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
             ++rc.n_batch;
             f3 q[SE_SPEC];
@@ -1183,30 +1171,6 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 #pragma unroll
               for (int k = 0; k < 8; ++k) cv0[k] = m.vx[vi0[k]];
             }
-#if SE_RUN > 0
-            // A ray that has left one surface band and is on its way to the next crosses unallocated blocks in
-            // largesteps -- one block per step, every sample a (cold) brick that holds initValue().  While the batch
-            // is in flight the leaf bitmap is probed for the SE_RUN positions behind it; if the batch is consumed
-            // completely, the leading positions whose block is not allocated are consumed too: get() returns
-            // initValue() there, y == 0, so the step is `largestep` again and the loop's own additions are replayed.
-            // (A bit set by the allocation scan of the next frame, which may run concurrently, only ends the run early:
-            // that sample then goes through the voxel loads, which see the still untouched brick.)
-            uint32_t run_free = 0u;
-            const bool run_mode = prev_full && S == a.largestep;   // (not on a ray's first batches: most rays never see a run)
-            if (run_mode) {
-              f3 r = q[SE_SPEC - 1];
-#pragma unroll
-              for (int j = 0; j < SE_RUN; ++j) {
-                r = f3_add(r, f3_scale(S, dir));
-                const int rx = cvt_i32(a.inv_voxel * r.x), ry = cvt_i32(a.inv_voxel * r.y), rz = cvt_i32(a.inv_voxel * r.z);
-                const bool inside = in_volume(m, rx, ry, rz);
-                const uint32_t lin = inside ? block_linear(m, rx >> 3, ry >> 3, rz >> 3) : 0u;
-                const uint32_t w = m.lbits[lin >> 5];
-                run_free |= (!inside || !((w >> (lin & 31u)) & 1u)) ? (1u << j) : 0u;
-              }
-            }
-            bool broke = false;
-#endif
 #pragma unroll
             for (int i = 0; i < SE_SPEC; ++i) {
               if (!(t < tfar)) { done = true; break; }
@@ -1232,26 +1196,8 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
                 f_t = f_tt;
               }
               t += stepsize;
-#if SE_RUN > 0
-              if (stepsize != S) { S = stepsize; broke = true; break; }
-#else
               if (stepsize != S) { S = stepsize; break; }
-#endif
             }
-#if SE_RUN > 0
-            prev_full = !done && !broke && S == a.largestep;
-            if (run_mode && prev_full) {   // every sample of the batch was used and the step is still `largestep`
-#pragma unroll
-              for (int j = 0; j < SE_RUN; ++j) {
-                if (!(t < tfar)) { done = true; break; }
-                if (!((run_free >> j) & 1u)) break;
-                if (STATS) ++n_get;
-                stepsize = a.largestep;
-                position = f3_add(position, f3_scale(stepsize, dir));
-                t += stepsize;
-              }
-            }
-#endif
           }
           if (f_tt < 0) {
             t = t + stepsize * f_tt / (f_t - f_tt);

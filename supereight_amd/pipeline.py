@@ -81,10 +81,33 @@ EXPORTS = {
 }
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so
+    (torch/lib, found through an RPATH), libse_hip.so is linked against /opt/rocm's.  Loaded side by side, the copy that
+    initialises second finds the GPU taken ("No HIP GPUs are available" from torch when libse_hip.so ran first).  Both
+    copies carry the soname libamdhip64.so.7, so mapping torch's copy by path before libse_hip.so makes the dynamic
+    loader resolve both users to that one object, whichever of them touches the GPU first.  No torch installed (or
+    already imported: the soname is then mapped): nothing to do."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for base in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(base, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load_library(rebuild: bool = True):
     """Load libse_hip.so (building it with hipcc first if it is missing or stale)."""
     global _LIB
     if _LIB is None:
+        _share_torch_hip_runtime()
         path = _build.LIB
         alt = os.environ.get("SE_HIP_LIB")   # A/B of kernel variants built to another path (tools/)
         if alt:

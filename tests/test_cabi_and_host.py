@@ -126,3 +126,19 @@ def test_raw_stream_with_groundtruth_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.gt").write_text("0 1 2 3\n")
         rawio.read_groundtruth(str(tmp_path / "bad.gt"))
+
+
+def test_one_hip_runtime_per_process():
+    """libse_hip.so first, torch second (the order that used to leave torch with "No HIP GPUs are available"): the
+    process must end up with ONE libamdhip64 mapped (pipeline._share_torch_hip_runtime)."""
+    import subprocess
+    import sys
+    code = ("from supereight_amd.pipeline import load_library\n"
+            "load_library(rebuild=False)\n"
+            "import torch\n"
+            "m = open('/proc/self/maps').read().split('\\n')\n"
+            "print(len({l.split()[-1] for l in m if 'libamdhip64' in l}), len({l.split()[-1] for l in m if 'libhsa-runtime64' in l}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-2:] == ["1", "1"], out.stdout
