@@ -126,6 +126,19 @@ int se_hip_set_exchange(se_hip_pipeline* p, void* nccl_comm, void* nccl_all_gath
 int se_hip_alloc_exchange(se_hip_pipeline* p, uint64_t* recv_device, int64_t words);
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t integration_rate,
                            float mu, uint32_t frame);
+/* Sharded sweep -- SURVEY 8(e) option 4, the alternative to the replicated sweep of projective_functor::apply
+ * (projective_functor.hpp:139-160) above; measured and priced in DESIGN.md section 7, off by default.  Replica `rank` of
+ * `world` updates only the blocks it owns (owner = (bx + by + bz) mod world, block units) and packs, for each of them, its
+ * position, its new active flag and -- if any voxel was in view -- its 512 voxels into the caller's send segment of
+ * se_hip_sweep_shard_bytes(cap_bricks) bytes, cap_bricks a multiple of 64: [u64 counts x 64][u32 records x cap][float vx
+ * x 512 x cap][float vy x 512 x cap], counter c over the records [c * cap / 64, (c + 1) * cap / 64).  After the caller's all-gather of the segments (rank order), se_hip_apply_bricks writes the other replicas'
+ * records into this replica's map on the main stream; se_hip_brick_exchange issues that all-gather itself
+ * (se_hip_set_exchange) on the main stream and then applies.  A segment that overflows makes the next stage call fail with
+ * SE_HIP_E_CAPACITY.  OFusion's node values stay replicated (every replica updates every node).  world <= 1 switches it off. */
+size_t se_hip_sweep_shard_bytes(size_t cap_bricks);
+int se_hip_set_sweep_shard(se_hip_pipeline* p, int32_t rank, int32_t world, void* send_device, size_t cap_bricks);
+int se_hip_apply_bricks(se_hip_pipeline* p, const void* recv_device, int32_t world);
+int se_hip_brick_exchange(se_hip_pipeline* p, void* recv_device);
 
 /* One frame of the loop of se_apps/src/benchmark.cpp:148-167 in one call: hand-over of a device-resident float_depth_
  * (NULL = keep the current depth image), then integration(), then raycasting() with the same pose -- exactly
@@ -209,7 +222,8 @@ int se_hip_dump_mesh(se_hip_pipeline* p, const char* filename);
 #define SE_HIP_K_ALLOC_COMMIT 1
 #define SE_HIP_K_INTEGRATE 2 /* block sweep + node sweep, one launch */
 #define SE_HIP_K_RAYCAST 3
-#define SE_HIP_K_COUNT 4
+#define SE_HIP_K_APPLY_BRICKS 4 /* sharded sweep: the other replicas' bricks written into this map */
+#define SE_HIP_K_COUNT 5
 /* HIP-event timing of every kernel launch on the handle's stream (off by default). */
 int se_hip_enable_timing(se_hip_pipeline* p, int32_t on);
 /* sum of launch durations [ms] and number of launches per kernel since the last reset */

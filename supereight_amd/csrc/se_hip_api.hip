@@ -86,6 +86,10 @@ struct se_hip_pipeline {
   void* xcomm = nullptr;
   int (*xgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int xworld = 0;
+  // sharded sweep (se_hip_set_sweep_shard): owner-computes + brick exchange instead of the replicated sweep
+  int shard_world = 0, shard_rank = 0;
+  unsigned char* shard_send = nullptr;   // caller's send segment
+  size_t shard_cap = 0;                  // bricks per segment
   bool mc_table_ready = false;   // SE_MC_TRI uploaded to constant memory
   unsigned long long* mesh_ctr = nullptr;
   bool filter_input = false;   // preprocessing(..., filterInput): tracking sees the bilateral-filtered depth
@@ -418,6 +422,7 @@ int check(se_hip_pipeline* p) {
 // (a frame late at most) instead of carrying on with a truncated key list or a map that lost octants.
 int check_overflow(se_hip_pipeline* p) {
   const uint32_t o = p->ctr_host[C_OVERFLOW];
+  if (o == 3) return fail(SE_HIP_E_CAPACITY, "brick exchange segment overflow: the peers missed block updates (raise cap_bricks of se_hip_set_sweep_shard)");
   if (o) return fail(SE_HIP_E_CAPACITY, o == 2 ? "new-key list overflow: blocks were allocated locally but not reported to the peers (raise the exchange capacity)"
                                               : "block / node pool exhausted (raise max_blocks)");
   return SE_HIP_OK;
@@ -882,6 +887,43 @@ int se_hip_alloc_exchange(se_hip_pipeline* p, uint64_t* recv_device, int64_t wor
   return se_hip_alloc_commit(p, recv_device, p->xworld, words);
 }
 
+size_t se_hip_sweep_shard_bytes(size_t cap_bricks) { return SE_SHARD_SUB * 8 + cap_bricks * 4 + cap_bricks * 4096; }
+
+int se_hip_set_sweep_shard(se_hip_pipeline* p, int32_t rank, int32_t world, void* send_device, size_t cap_bricks) {
+  if (int r = check(p)) return r;
+  if (world <= 1) { p->shard_world = 0; p->shard_send = nullptr; p->shard_cap = 0; return SE_HIP_OK; }
+  if (rank < 0 || rank >= world || !send_device || cap_bricks == 0 || (cap_bricks % SE_SHARD_SUB) || cap_bricks > ((size_t)1 << 30))
+    return fail(SE_HIP_E_INVALID, "bad argument (cap_bricks must be a positive multiple of 64)");
+  p->shard_world = world; p->shard_rank = rank; p->shard_send = (unsigned char*)send_device; p->shard_cap = cap_bricks;
+  return SE_HIP_OK;
+}
+
+int se_hip_apply_bricks(se_hip_pipeline* p, const void* recv_device, int32_t world) {
+  if (int r = check(p)) return r;
+  if (p->shard_world <= 1 || world != p->shard_world || !recv_device) return fail(SE_HIP_E_INVALID, "no sharded sweep set (se_hip_set_sweep_shard) or bad argument");
+  {
+    ScopedTimer t(p, SE_HIP_K_APPLY_BRICKS);
+    const size_t est = (size_t)p->ctr_host[C_BLOCKS] / (size_t)world + 1024;   // records per segment, roughly
+    const size_t wgs = std::min<size_t>((est + 3) / 4, 16384);
+    const dim3 grid((unsigned)(((wgs + 15) / 16) * 16), (unsigned)world);   // 4 waves per workgroup: a multiple of SE_SHARD_SUB waves
+    hipLaunchKernelGGL(k_apply_bricks, grid, dim3(SE_WG), 0, p->stream, p->map, (const unsigned char*)recv_device,
+                       se_hip_sweep_shard_bytes(p->shard_cap), (uint32_t)p->shard_cap, p->shard_rank);
+  }
+  // the next frame's scan reads the active flags this kernel wrote: it is what that scan has to wait for
+  if (!p->host_gate) hipEventRecord(p->ev_sweep, p->stream);
+  HIP_TRY(hipGetLastError());
+  return SE_HIP_OK;
+}
+
+int se_hip_brick_exchange(se_hip_pipeline* p, void* recv_device) {
+  if (int r = check(p)) return r;
+  if (!p->xgather) return fail(SE_HIP_E_INVALID, "no exchange set (se_hip_set_exchange)");
+  if (p->shard_world <= 1 || p->xworld != p->shard_world || !recv_device) return fail(SE_HIP_E_INVALID, "no sharded sweep set (se_hip_set_sweep_shard) or bad argument");
+  const int rc = p->xgather(p->shard_send, recv_device, se_hip_sweep_shard_bytes(p->shard_cap), /* ncclUint8 */ 1, p->xcomm, p->stream);
+  if (rc != 0) return fail(SE_HIP_E_DEVICE, "ncclAllGather failed with code " + std::to_string(rc));
+  return se_hip_apply_bricks(p, recv_device, p->xworld);
+}
+
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
   if (int r = check(p)) return r;
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
@@ -928,6 +970,14 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
     a.zero_count = other ? p->newkeys_own2 : p->newkeys_own;
     p->own_clean[other] = true;
     p->own_next = other;
+  }
+  if (p->shard_world > 1) {
+    a.shard_world = p->shard_world; a.shard_rank = p->shard_rank; a.shard_cap = (uint32_t)p->shard_cap;
+    a.shard_count = (unsigned long long*)p->shard_send;
+    a.shard_recs = (uint32_t*)(p->shard_send + SE_SHARD_SUB * 8);
+    a.shard_vx = (float*)(p->shard_send + SE_SHARD_SUB * 8 + p->shard_cap * 4);
+    a.shard_vy = a.shard_vx + p->shard_cap * 512;
+    HIP_TRY(hipMemsetAsync(p->shard_send, 0, SE_SHARD_SUB * 8, p->stream));
   }
   if (p->prio_hint) {
     a.tile_cost = p->tile_cost; a.prio_thr = p->prio_thr;
@@ -1231,8 +1281,7 @@ static int fetch_counters(se_hip_pipeline* p) {
   if (int r = join_scan(p)) return r;
   HIP_TRY(hipMemcpyAsync(p->ctr_host, p->map.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
-  if (p->ctr_host[C_OVERFLOW]) return fail(SE_HIP_E_CAPACITY, p->ctr_host[C_OVERFLOW] == 2 ? "new-key list overflow" : "block / node pool exhausted (raise max_blocks)");
-  return SE_HIP_OK;
+  return check_overflow(p);
 }
 
 // ---------------------------------------------------------------------------------- mesh export

@@ -316,12 +316,15 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_commit(DevMap m, const unsigned
 // of frame f it inserts into tab[] / the lists but leaves occ[] (which that raycast is walking)
 // alone; this kernel then sets the bits of every inserted octant and of all its ancestors.
 struct OccLists { const unsigned long long* lists; int nlists; long long stride_words; };   // [count, keys...] per list
-__device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L) {
+// Done by the first `nwg` workgroups of the launch only: every participating thread reads each list's count word first
+// (nlists dependent round trips), which the ~10^4 other waves of a sweep launch need not pay for.
+__device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L, unsigned nwg) {
+  if (blockIdx.x >= nwg) return;
   for (int li = 0; li < L.nlists; ++li) {
     const unsigned long long* list = L.lists + (long long)li * L.stride_words;
     unsigned long long n = list[0];
     if (n > (unsigned long long)(L.stride_words - 1)) n = (unsigned long long)(L.stride_words - 1);
-    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)nwg * blockDim.x) {
       const unsigned long long raw = list[1 + i];
       if (raw & SE_KEY_ACTIVATE) continue;
       const int level = (int)(raw & 0x1FFull);
@@ -338,7 +341,7 @@ __device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L)
     }
   }
 }
-__global__ __launch_bounds__(SE_WG) void k_occ_commit(DevMap m, OccLists L) { se_occ_commit(m, L); }
+__global__ __launch_bounds__(SE_WG) void k_occ_commit(DevMap m, OccLists L) { se_occ_commit(m, L, gridDim.x); }
 
 // unique_multiscale keeps keys[0] whatever its level (se_core/include/se/algorithms/unique.hpp:64-79):
 // when the smallest key of a frame's list (after filter_ancestors) is a coarse octant, the
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(SE_WG) void k_zero_chain(DevMap m, const unsigned l
 // ------------------------------------------------------------------------------------------
 // integration: projective_map (se_core/include/se/functors/projective_functor.hpp:45-176)
 // ------------------------------------------------------------------------------------------
+#define SE_SHARD_SUB 64   // sub-segments (and record counters) of a sharded-sweep send segment
 struct IntegArgs {
   float R[9], t[3];        // Tcw = SE3f(pose).inverse()
   float K3[9];             // K.topLeftCorner<3,3>()
@@ -426,6 +430,16 @@ struct IntegArgs {
   int n_tiles;
   int* prio_thr;
   int prio_permille[3];    // share of the tiles (per mille) that get priority >= 1 / >= 2 / 3
+  // Sharded sweep (se_hip_set_sweep_shard; SURVEY 8(e) option 4, measured in DESIGN 7): of R replicas, this one updates only
+  // the blocks it owns, owner = (bx + by + bz) mod R in block units, and packs each of them into its send segment --
+  // [counts][records: position | active << 31][vx bricks][vy bricks] -- which k_apply_bricks writes into the other replicas'
+  // maps after the all-gather.  shard_world <= 1: off.  SE_SHARD_SUB counters, each over 1/SE_SHARD_SUB of the records.
+  int shard_world, shard_rank;
+  unsigned long long* shard_count;
+  uint32_t* shard_recs;
+  float* shard_vx;
+  float* shard_vy;
+  uint32_t shard_cap;
 };
 
 // One workgroup: 256-bin histogram of the tile costs, thresholds = smallest cost v with #(cost >= v) <= fraction * n.
@@ -603,12 +617,13 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   // without a device-to-host copy between this kernel and the raycast)
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
   if (a.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_count = 0ull;
-  if (a.commit_occ) se_occ_commit(m, a.occ_lists);   // nothing in this kernel reads occ[]; the raycast that follows does
+  if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x, 64u));   // nothing in this kernel reads occ[]; the raycast that follows does
   __shared__ unsigned s_hist[256];
   if (a.prio_thr && blockIdx.x == 0) se_prio_thresholds(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille);
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
+    if (a.shard_world > 1 && (unsigned)((bx >> 3) + (by >> 3) + (bz >> 3)) % (unsigned)a.shard_world != (unsigned)a.shard_rank) continue;
     const uint32_t slot = block_slot(m, b, bp);
     if (!m.bactive[slot] && !se_in_frustum(a, bx, by, bz)) continue;
     if (STATS && lane == 0) ++swept;
@@ -671,10 +686,66 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     }
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
+    if (a.shard_world > 1) {   // the other replicas get this block's flag and, if anything of it was in view, its voxels
+      // record slots are handed out by SE_SHARD_SUB counters, each over its own 1/SE_SHARD_SUB of the segment (one
+      // counter for the ~10 k blocks of a frame is 50-70 us of serialised atomics: one word takes ~90 of them per us)
+      const uint32_t sub = (uint32_t)wave & (SE_SHARD_SUB - 1), subcap = a.shard_cap / SE_SHARD_SUB;
+      uint32_t rec = 0u;
+      if (lane == 0) rec = (uint32_t)atomicAdd(a.shard_count + sub, 1ull);
+      rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec);
+      const bool fits = rec < subcap;
+      rec += sub * subcap;
+      if (fits) {
+        if (lane == 0) a.shard_recs[rec] = bp | (any ? 0x80000000u : 0u);
+        if (any) {
+          float* sx = a.shard_vx + (size_t)rec * 512 + lane;
+          float* sy = a.shard_vy + (size_t)rec * 512 + lane;
+#pragma unroll
+          for (int zi = 0; zi < 8; ++zi) { sx[zi * 64] = vx[zi]; sy[zi * 64] = vy[zi]; }
+        }
+      } else if (lane == 0) {
+        m.ctr[C_OVERFLOW] = 3u;   // brick exchange segment too small: the peers miss this block's update
+      }
+    }
   }
   if (STATS && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
   for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG)
     se_update_node_corner<OFUSION>(m, depthmap, a, tid);
+}
+
+// The receiving side of the sharded sweep: every record of the other replicas' segments (grid.y = segment) is written
+// into this replica's map -- the active flag always, the 512 voxels if the owner saw any of them.  One wave per record.
+__global__ __launch_bounds__(SE_WG) void k_apply_bricks(DevMap m, const unsigned char* __restrict__ recv, size_t seg_bytes, uint32_t cap, int self) {
+  const int seg = blockIdx.y;
+  if (seg == self) return;
+  const unsigned char* base = recv + (size_t)seg * seg_bytes;
+  const unsigned long long* counts = (const unsigned long long*)base;
+  const uint32_t* recs = (const uint32_t*)(base + SE_SHARD_SUB * 8);
+  const float* bvx = (const float*)(base + SE_SHARD_SUB * 8 + (size_t)cap * 4);
+  const float* bvy = bvx + (size_t)cap * 512;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * SE_WG + threadIdx.x) >> 6, nwaves = (gridDim.x * SE_WG) >> 6;
+  const uint32_t subcap = cap / SE_SHARD_SUB;
+  // wave w walks sub-segment w mod SE_SHARD_SUB (the grid has a multiple of SE_SHARD_SUB waves)
+  const uint32_t sub = wave & (SE_SHARD_SUB - 1);
+  const uint32_t n = (uint32_t)min(counts[sub], (unsigned long long)subcap);
+  for (uint32_t j = wave / SE_SHARD_SUB; j < n; j += nwaves / SE_SHARD_SUB) {
+    const uint32_t i = sub * subcap + j;
+    const uint32_t r = recs[i], bp = r & 0x3FFFFFFFu;
+    const int bx = (int)(bp & 1023u), by = (int)((bp >> 10) & 1023u), bz = (int)(bp >> 20);
+    const uint32_t e = m.dense ? block_linear(m, bx, by, bz) + 1u : m.tab[leaf_index(m, bx, by, bz)];
+    if (e == 0u || e == SE_PENDING) continue;   // (cannot happen: the block sets are equal after the key exchange)
+    const uint32_t slot = e - 1u;
+    if (lane == 0) m.bactive[slot] = (unsigned char)(r >> 31);
+    if (r >> 31) {
+      const float* sx = bvx + (size_t)i * 512 + lane;
+      const float* sy = bvy + (size_t)i * 512 + lane;
+      float* dx = m.vx + (size_t)slot * 512 + lane;
+      float* dy = m.vy + (size_t)slot * 512 + lane;
+#pragma unroll
+      for (int zi = 0; zi < 8; ++zi) { dx[zi * 64] = sx[zi * 64]; dy[zi * 64] = sy[zi * 64]; }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------

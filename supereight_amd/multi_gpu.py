@@ -71,7 +71,7 @@ class ShardedPipeline:
 
     def __init__(self, input_size, volume_resolution, volume_dimension, field_type, rank, world, device,
                  small_words: int = 0, big_words: int = 0, max_blocks: int = 0, group=None,
-                 exchange_always: bool = False):
+                 exchange_always: bool = False, shard_sweep: bool = False, brick_cap: int = 0):
         import torch
         from .pipeline import DenseSLAMPipeline
         self.torch = torch
@@ -114,6 +114,37 @@ class ShardedPipeline:
             self._pg = pg if (not self.gloo and hasattr(pg, "_allgather_base")) else None
             self.direct = (not self.gloo) and self._direct_rccl(pg, dev)
         self.p.set_stream(self.main.cuda_stream)
+        # Sharded sweep (SURVEY 8e option 4; off by default, DESIGN.md section 7 has the price): owner-computes integration
+        # + an all-gather of the updated bricks instead of every replica sweeping every block.
+        self.shard_sweep = bool(shard_sweep) and world > 1
+        if self.shard_sweep:
+            if not brick_cap:   # blocks in view per frame ~ surface area in blocks; x2 for ownership imbalance
+                brick_cap = int(2 * 20000 * max(1, int(volume_resolution) // 512) ** 2 / world)
+            self.brick_cap = 64 * ((int(brick_cap) + 63) // 64)   # 64 sub-segments with a record counter each
+            seg = self.p.sweep_shard_bytes(self.brick_cap)
+            self.bsend = torch.zeros(seg, dtype=torch.uint8, device=dev)
+            self.brecv = torch.zeros(world * seg, dtype=torch.uint8, device=dev)
+            self.p.set_sweep_shard(rank, world, self.bsend.data_ptr(), self.brick_cap, keepalive=self.bsend)
+
+    def _exchange_bricks(self):
+        """All-gather of the send segments on the MAIN stream (behind the sweep that packed them), then apply."""
+        p, torch = self.p, self.torch
+        if self.direct:
+            p.brick_exchange(self.brecv.data_ptr())
+            return
+        with torch.cuda.stream(self.main):
+            if self.gloo:
+                import torch.distributed as dist
+                host = self.bsend.cpu()
+                out = torch.empty(self.world * host.numel(), dtype=host.dtype)
+                dist.all_gather_into_tensor(out, host, group=self.group)
+                self.brecv.copy_(out)
+            elif self._pg is not None:
+                self._pg._allgather_base(self.brecv, self.bsend).wait()
+            else:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(self.brecv, self.bsend, group=self.group)
+        p.apply_bricks(self.brecv.data_ptr(), self.world)
 
     def _direct_rccl(self, pg, dev) -> bool:
         """Hands the process group's ncclComm_t and the address of ncclAllGather (of the RCCL torch has loaded)
@@ -166,6 +197,8 @@ class ShardedPipeline:
                 elif self.direct:
                     p.alloc_exchange(recv.data_ptr(), words)
                     p.integrate_sweep(k, integration_rate, mu, frame)
+                    if self.shard_sweep:
+                        self._exchange_bricks()
                     p.raycasting(k, mu, frame)
                     return ran
                 else:
@@ -177,6 +210,8 @@ class ShardedPipeline:
                     # no stream join here: se_hip_alloc_commit fences the scan stream (= xs) itself
                 p.alloc_commit(recv.data_ptr(), self.world, words)
             p.integrate_sweep(k, integration_rate, mu, frame)
+            if self.shard_sweep:
+                self._exchange_bricks()
         p.raycasting(k, mu, frame)
         return ran
 

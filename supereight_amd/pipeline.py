@@ -17,7 +17,7 @@ import numpy as np
 from . import build as _build
 
 SDF, OFUSION = 0, 1
-KERNELS = ("alloc_scan", "alloc_commit", "integrate", "raycast")
+KERNELS = ("alloc_scan", "alloc_commit", "integrate", "raycast", "apply_bricks")
 STAT_NAMES = ("probes", "new_keys", "swept", "nodes", "gets", "interps", "grads", "hits",
               "clk_iter", "clk_march", "clk_grad", "clk_wave_max", "clk_stage", "r13", "r14", "r15")
 
@@ -54,6 +54,10 @@ EXPORTS = {
     "se_hip_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "se_hip_alloc_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_sweep_shard_bytes": (C.c_size_t, [C.c_size_t]),
+    "se_hip_set_sweep_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "se_hip_apply_bricks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "se_hip_brick_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
     "se_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
@@ -309,6 +313,20 @@ class DenseSLAMPipeline:
 
     def alloc_exchange(self, recv_ptr: int, words: int):
         self._check(self.lib.se_hip_alloc_exchange(self._h, C.c_void_p(recv_ptr), words))
+
+    def sweep_shard_bytes(self, cap_bricks: int) -> int:
+        return int(self.lib.se_hip_sweep_shard_bytes(cap_bricks))
+
+    def set_sweep_shard(self, rank: int, world: int, send_ptr: int, cap_bricks: int, keepalive=None):
+        """Sharded sweep (SURVEY 8e option 4): this replica integrates the blocks it owns and packs them into `send_ptr`."""
+        self._check(self.lib.se_hip_set_sweep_shard(self._h, rank, world, C.c_void_p(send_ptr), cap_bricks))
+        self._shard_keepalive = keepalive
+
+    def apply_bricks(self, recv_ptr: int, world: int):
+        self._check(self.lib.se_hip_apply_bricks(self._h, C.c_void_p(recv_ptr), world))
+
+    def brick_exchange(self, recv_ptr: int):
+        self._check(self.lib.se_hip_brick_exchange(self._h, C.c_void_p(recv_ptr)))
 
     def integrate_sweep(self, k, integration_rate: int, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, self._pose_cm, self._k(k),

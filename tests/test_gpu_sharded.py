@@ -66,6 +66,95 @@ def test_sharded_replicas_equal_single(field, mu, R, H):
     single.close()
 
 
+@pytest.mark.parametrize("field,mu,R,pooled", [(SDF, 0.1, 2, False), (SDF, 0.1, 8, False), (OFUSION, 0.02, 4, False), (SDF, 0.1, 4, True)],
+                         ids=["sdf-2", "sdf-8", "ofusion-4", "sdf-4-pooled"])
+def test_sharded_sweep_equals_single(field, mu, R, pooled):
+    """SURVEY 8(e) option 4 behind its flag: every replica integrates only the blocks it owns and receives the others'
+    bricks (the all-gather of the send segments is emulated by torch.cat, as for the key lists above).  Map and stitched
+    raycast must equal the unsharded pipeline's, bit for bit -- also when the bricks live in the pool (slots differ
+    between replicas, positions do not)."""
+    import torch
+    W, H, N, dim, frames = 160, 120, 256, 2.4, 6
+    dev = torch.device("cuda", 0)
+    stream = SyntheticStream(W, H, dim)
+    mb = 20000 if pooled else 0
+    single = DenseSLAMPipeline((W, H), N, dim, field_type=field, max_blocks=mb)
+    parts = row_partition(H, R)
+    reps = [DenseSLAMPipeline((W, H), N, dim, field_type=field, rows=parts[r], max_blocks=mb) for r in range(R)]
+    words, cap = 1 << 15, 4096
+    seg = reps[0].sweep_shard_bytes(cap)
+    send = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(R)]
+    bsend = [torch.zeros(seg, dtype=torch.uint8, device=dev) for _ in range(R)]
+    for r in range(R):
+        reps[r].set_new_keys_buffer(send[r].data_ptr(), words, keepalive=send[r])
+        reps[r].set_sweep_shard(r, R, bsend[r].data_ptr(), cap, keepalive=bsend[r])
+    packed = 0
+    for f in range(frames):
+        depth, pose = stream.depth(f), stream.pose(f)
+        single.set_depth(depth); single.setPose(pose)
+        single.integration(stream.k, 1, mu, f)
+        single.raycasting(stream.k, mu, f)
+        for p in reps:
+            p.set_depth(depth); p.setPose(pose)
+            assert p.alloc_scan(stream.k, 1, mu, f)
+        for p in reps:
+            p.sync()
+        recv = torch.cat(send)
+        torch.cuda.synchronize()
+        for p in reps:
+            p.alloc_commit(recv.data_ptr(), R, words)
+            p.integrate_sweep(stream.k, 1, mu, f)
+        for p in reps:
+            p.sync()
+        brecv = torch.cat(bsend)                     # what the all-gather of the segments delivers on every rank
+        torch.cuda.synchronize()
+        counts = torch.stack([b[:512].view(torch.int64) for b in bsend]).cpu().numpy()   # 64 record counters per segment
+        assert counts.max() <= cap // 64 and counts.sum(axis=1).min() > 0, counts
+        packed += int(counts.sum())
+        for p in reps:
+            p.apply_bricks(brecv.data_ptr(), R)
+            p.raycasting(stream.k, mu, f)
+        for p in reps:
+            p.sync()
+    c, x, y, a = single.blocks()
+    code, side, nx, ny = single.nodes()
+    v, n = single.vertex_normal()
+    assert len(c) > 500 and packed > len(c)
+    order = np.lexsort((c[:, 0], c[:, 1], c[:, 2]))
+    vs, ns = np.zeros_like(v), np.zeros_like(n)
+    for r, p in enumerate(reps):
+        rc, rx, ry, ra = p.blocks()
+        ro = np.lexsort((rc[:, 0], rc[:, 1], rc[:, 2]))
+        assert rc.shape == c.shape and (rc[ro] == c[order]).all()
+        assert (rx[ro].view(np.uint32) == x[order].view(np.uint32)).all() and (ry[ro].view(np.uint32) == y[order].view(np.uint32)).all()
+        assert (ra[ro] == a[order]).all()
+        rcode, rside, rnx, rny = p.nodes()
+        assert (rcode == code).all() and (rnx.view(np.uint32) == nx.view(np.uint32)).all() and (rny.view(np.uint32) == ny.view(np.uint32)).all()
+        rv, rn = p.vertex_normal()
+        b, e = parts[r]
+        vs[b:e], ns[b:e] = rv[b:e], rn[b:e]
+        p.close()
+    assert (vs.view(np.uint32) == v.view(np.uint32)).all() and (ns.view(np.uint32) == n.view(np.uint32)).all()
+    single.close()
+
+
+def test_brick_segment_overflow_is_reported():
+    import torch
+    from supereight_amd.pipeline import SeHipError
+    W, H, N, dim, mu = 160, 120, 256, 2.4, 0.1
+    stream = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+    cap = 64                                        # rank 0 of 2 owns ~1000 of the blocks frame 0 brings into view
+    bsend = torch.zeros(p.sweep_shard_bytes(cap), dtype=torch.uint8, device="cuda")
+    p.set_sweep_shard(0, 2, bsend.data_ptr(), cap, keepalive=bsend)
+    with pytest.raises(SeHipError, match="brick exchange segment overflow"):
+        for f in range(3):
+            p.set_depth(stream.depth(f)); p.setPose(stream.pose(f))
+            p.integration(stream.k, 1, mu, f)
+            p.sync()
+    p.close()
+
+
 def test_key_list_overflow_is_reported_on_the_frame_path():
     """A key list that does not fit its exchange buffer must not go unnoticed: the peers would miss blocks and the
     replicas would diverge.  The stage calls of the following frame fail with SE_HIP_E_CAPACITY."""
