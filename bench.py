@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=4, help="repetitions of the CPU baseline sample (the fastest is reported, all are listed)")
     ap.add_argument("--sustain", type=int, default=200, help="N = 1: after the K contract steps keep going until this many frames have been timed in total (0 = off)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU clock ramp-up before the warm-up frames (see prewarm())")
+    ap.add_argument("--shard-sweep", action="store_true", help="N > 1: owner-computes integration + brick all-gather instead of the replicated sweep (SURVEY 8e option 4; DESIGN.md section 7: measured slower, off by default)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra N = 1 legs (closed loop, tracking on, pooled bricks)")
     ap.add_argument("--mode-frames", type=int, default=60, help="timed frames of each extra leg")
     ap.add_argument("--detail", type=str, default="", help="write a detailed JSON report to this path")
@@ -335,7 +336,7 @@ def main():
 
     # the pipeline is created BEFORE the pre-warm and the scratch map is freed AFTER the timed regions: allocating or
     # freeing gigabytes idles the GPU for tens of milliseconds, long enough for the clocks to drop again
-    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank)
+    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank, shard_sweep=args.shard_sweep)
     prewarm_frames, scratch = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else (0, None)
 
     def barrier():
@@ -396,7 +397,7 @@ def main():
             "config": {"workload": f"{stream_name} {W}x{H} -> {N}^3 / {dim} m "
                                    f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
                                    f"GT poses, frames {warm}..{warm + K - 1} timed",
-                       "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists",
+                       "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists" + (", sweep sharded by block owner + RCCL all-gather of the updated bricks" if sp.shard_sweep else ""),
                        "blocks_allocated": nblocks, "nodes_allocated": nnodes,
                        "prewarm": f"{prewarm_frames} untimed frames on a scratch map before the W warm-up frames (GPU clock ramp, see bench.py prewarm())"},
         }
