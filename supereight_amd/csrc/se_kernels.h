@@ -430,6 +430,7 @@ struct IntegArgs {
   int n_tiles;
   int* prio_thr;
   int prio_permille[3];    // share of the tiles (per mille) that get priority >= 1 / >= 2 / 3
+  uint32_t* ray_order;     // out: the tile PAIRS (one raycast workgroup each) by descending previous cost (RayArgs::ray_order); may be null
   // Sharded sweep (se_hip_set_sweep_shard; SURVEY 8(e) option 4, measured in DESIGN 7): of R replicas, this one updates only
   // the blocks it owns, owner = (bx + by + bz) mod R in block units, and packs each of them into its send segment --
   // [counts][records: position | active << 31][vx bricks][vy bricks] -- which k_apply_bricks writes into the other replicas'
@@ -442,22 +443,63 @@ struct IntegArgs {
   uint32_t shard_cap;
 };
 
-// One workgroup: 256-bin histogram of the tile costs, thresholds = smallest cost v with #(cost >= v) <= fraction * n.
-__device__ __forceinline__ void se_prio_thresholds(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist, const int* permille) {
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
+// One workgroup turns the previous raycast's per-tile costs into the schedule of the next one:
+//  * 256-bin histogram -> priority thresholds = smallest cost v with #(cost >= v) <= fraction * n;
+//  * counting sort of the tile pairs (tiles 2p, 2p+1: the two waves of one raycast workgroup) by their mean cost ->
+//    order[] = pairs, costliest first (ties in arrival order: scheduling only, never results).
+// cost[] is padded (16-byte loads); hist = 768 words of LDS.
+__device__ __forceinline__ void se_ray_schedule(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist, const int* permille,
+                                                uint32_t* __restrict__ order) {
+  unsigned* phist = hist + 256;   // pairs per mean cost
+  unsigned* base = hist + 512;    // first slot of each cost in order[]
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0u;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[min((int)cost[i], 255)], 1u);
+  const int per = 8 * ((n + 8 * (int)blockDim.x - 1) / (8 * (int)blockDim.x));   // tiles per thread, a multiple of 8
+  const int first = (int)threadIdx.x * per;
+  for (int v = 0; v < per; v += 8) {
+    if (first + v >= n) break;
+    const uint4 q = *(const uint4*)(cost + first + v);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned c0 = w[e] & 0xFFFFu, c1 = (first + v + 2 * e + 1 < n) ? (w[e] >> 16) : 0u;
+      if (first + v + 2 * e < n) {
+        atomicAdd(&hist[min(c0, 255u)], 1u);
+        if (first + v + 2 * e + 1 < n) atomicAdd(&hist[min(c1, 255u)], 1u);
+        atomicAdd(&phist[min((c0 + c1) >> 1, 255u)], 1u);
+      }
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned lim[3] = {(unsigned)((long long)n * permille[0] / 1000), (unsigned)((long long)n * permille[1] / 1000), (unsigned)((long long)n * permille[2] / 1000)};
     int t[3] = {256, 256, 256};
-    unsigned acc = 0u;
-    for (int v = 255; v >= 1; --v) {
+    unsigned acc = 0u, pacc = 0u;
+    for (int v = 255; v >= 0; --v) {
+      base[v] = pacc;                    // pairs with a higher mean cost come first
+      pacc += phist[v];
       acc += hist[v];
+      if (v >= 1) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) if (acc <= lim[k]) t[k] = v;
+        for (int k = 0; k < 3; ++k) if (acc <= lim[k]) t[k] = v;
+      }
     }
     thr[0] = t[0]; thr[1] = t[1]; thr[2] = t[2];
+  }
+  __syncthreads();
+  if (order) {
+    for (int v = 0; v < per; v += 8) {
+      if (first + v >= n) break;
+      const uint4 q = *(const uint4*)(cost + first + v);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (first + v + 2 * e < n) {
+          const unsigned c0 = w[e] & 0xFFFFu, c1 = (first + v + 2 * e + 1 < n) ? (w[e] >> 16) : 0u;
+          const unsigned c = min((c0 + c1) >> 1, 255u);
+          order[base[c] + atomicSub(&phist[c], 1u) - 1u] = (uint32_t)((first + v) / 2 + e);   // phist[c] counts down: a unique slot of c's range
+        }
+    }
   }
 }
 
@@ -618,8 +660,8 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
   if (a.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_count = 0ull;
   if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x, 64u));   // nothing in this kernel reads occ[]; the raycast that follows does
-  __shared__ unsigned s_hist[256];
-  if (a.prio_thr && blockIdx.x == 0) se_prio_thresholds(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille);
+  __shared__ unsigned s_hist[768];
+  if (a.prio_thr && blockIdx.x == 0) se_ray_schedule(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille, a.ray_order);
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
@@ -769,10 +811,17 @@ struct RayArgs {
   uint32_t cache_codes;  // heap codes below this value are staged (= 2 * 8^cache_levels)
   int has_deep;          // there are non-leaf levels beyond the staged ones (volumes > 512^3)
   int stack_depth;   // ray stack slots (= leaf level)
-  int xcd_swizzle;
-  // Scheduling hint (results do not depend on it): cost of every wave tile in the previous raycast launch,
-  // trips + 5 * march batches of its slowest ray.  A launch ends when its slowest waves end, and those are known in
-  // advance -- the silhouettes and depth edges of the previous frame -- so they start with a raised issue priority.
+  // Scheduling (results do not depend on it).  tile_cost[] = cost of every wave tile (8x8 pixels) in the previous
+  // raycast launch, trips + 5 * march batches of its slowest ray.  All waves of a 640x480 launch are resident from the
+  // first microsecond, every SIMD works through the 4-5 tiles the dispatcher gives it, and the launch lasts as long as the
+  // unluckiest SIMD: with workgroups in image order the cost sums per SIMD spread 3x (115..343 around a median of 179,
+  // tools/ray_diag.py) and the SIMD finish times 24..42 us follow them (correlation 0.85).  The dispatcher hands workgroup
+  // i to compute unit i mod n_cus (observed; a speed assumption only), so the integration sweep sorts the workgroups' tile
+  // pairs by previous cost (ray_order) and workgroup i takes the pair at position (i / n_cus, i mod n_cus) of a snake deal:
+  // every compute unit gets one pair of each cost stratum.  On top, the waves of the costliest tiles -- the silhouettes
+  // and depth edges of the previous frame -- run with a raised issue priority: their dependent-load chains are the longest.
+  const uint32_t* ray_order;   // ceil(n_tiles / 2) pair indices, costliest first (identity until the first sweep)
+  int n_cus;
   // Host gate: the first thread of the launch writes gate_seq to a pinned host word.  This launch starts only when the
   // integration sweep in front of it on the same queue has completed, so a host that sees the word knows that sweep is
   // done and may release the next frame's allocation scan on the other queue -- the dependency sweep(f) -> scan(f+1)
@@ -780,7 +829,7 @@ struct RayArgs {
   uint32_t* gate;
   uint32_t gate_seq;
   unsigned short* tile_cost;
-  const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_prio_thresholds)
+  const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
 #ifdef SE_DIAG
   int debug_phases;    // diagnostic build only: bit0 = skip march + gradient, bit1 = skip gradient, bit2 = skip the traversal (results are then wrong)
   uint32_t* diag_pix;  // per pixel: iterator trips | march batches << 16 (STATS variants)
@@ -1363,29 +1412,22 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   unsigned long long tk2 = tk1, tk3 = tk1;
   const FieldConst fc = se_field_const(m);
   const int lane = threadIdx.x & 63;
-  // Workgroup -> tile mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order; a speed assumption only) and
-  // every XCD has its own L2, so with the plain row-major order each of the 8 L2s ends up holding the bricks of the
-  // whole image.  xcd_swizzle = S > 1: the image is cut into supertiles of S x S wave tiles and supertile g belongs to
-  // XCD g % 8 -- each L2 then serves 1/8 of the bricks (plus supertile borders), and the 8-way interleave of small
-  // supertiles keeps the cheap / expensive image regions balanced (whole-image bands per XCD were measured slower).
+  // Workgroup -> tile pair: the snake deal of the cost-sorted pairs over the compute units (see RayArgs::ray_order)
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W;
-  int tile = blockIdx.x * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
-  int tx = tile % tiles_x, ty = tile / tiles_x;
-  if (a.xcd_swizzle > 1) {
-    const int S = a.xcd_swizzle, per_st = S * S / (SE_WG_RAY / 64);   // workgroups per supertile
-    const int tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
-    const int sx_n = (tiles_x + S - 1) / S;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int g = (j / per_st) * 8 + xcd;
-    const int t = (j % per_st) * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
-    tx = (g % sx_n) * S + (t % S);
-    ty = (g / sx_n) * S + (t / S);
-    tile = (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : 0;   // (diagnostic index only)
-    if (tx >= tiles_x) ty = 1 << 20;   // outside the image: fails the row test below
+  const int tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
+  const int n_tiles = tiles_x * tiles_y, n_pairs = (n_tiles + 1) >> 1;
+  int tile;
+  {
+    const int rnd = blockIdx.x / a.n_cus, cu = blockIdx.x - rnd * a.n_cus;
+    const int pos = rnd * a.n_cus + ((rnd & 1) ? a.n_cus - 1 - cu : cu);
+    const int pair = pos < n_pairs ? (int)a.ray_order[pos] : n_pairs;   // (positions of the last, partial round beyond the list: no pair)
+    tile = 2 * pair + (threadIdx.x >> 6);
   }
+  int tx = tile % tiles_x, ty = tile / tiles_x;
+  if (tile >= n_tiles) { tx = tiles_x; ty = 1 << 20; tile = 0; }   // no tile: fails the tests below
   const int px = tx * SE_TILE_W + (lane % SE_TILE_W);
   const int py = a.row_begin + ty * SE_TILE_H + (lane / SE_TILE_W);
-  const bool tile_in_image = tx < tiles_x && a.row_begin + ty * SE_TILE_H < a.row_end;
+  const bool tile_in_image = tx < tiles_x && ty < tiles_y;
   const int tile_slot = __builtin_amdgcn_readfirstlane(tile_in_image ? ty * tiles_x + tx : 0);
   unsigned my_cost = 0u;
   if (a.tile_cost) {

@@ -9,7 +9,7 @@ from supereight_amd.synthetic import SyntheticStream
 
 CFG = {"sdf512": (640, 480, 512, SDF, 0.1), "sdf1024": (640, 480, 1024, SDF, 0.1), "of512": (640, 480, 512, OFUSION, 0.008),
        "of512mu01": (640, 480, 512, OFUSION, 0.1), "sdf2048": (1280, 960, 2048, SDF, 0.1)}
-KNOBS = ("SE_HIP_XCD_SWIZZLE", "SE_HIP_PRIO", "SE_HIP_RAY_CACHE_LEVELS", "SE_HIP_NO_OVERLAP", "SE_HIP_DENSE", "SE_HIP_PRIO_SHARE")
+KNOBS = ("SE_HIP_RAY_DEAL", "SE_HIP_PRIO", "SE_HIP_RAY_CACHE_LEVELS", "SE_HIP_NO_OVERLAP", "SE_HIP_DENSE", "SE_HIP_PRIO_SHARE")
 
 def run(cfg, groups):
     W, H, N, field, mu = CFG[cfg]

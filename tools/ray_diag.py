@@ -61,8 +61,12 @@ T = end.max()
 print("resident waves over time:", [int(((start <= f * T) & (end > f * T)).sum()) for f in (0.02, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)], "T = %.1f us" % (T / 100.0))
 hw = wave[:, 7]
 xcc = (hw >> 28).astype(np.int64); hid = (hw & 0x0FFFFFFF).astype(np.int64)
-key = (xcc << 20) | (((hid >> 13) & 7) << 12) | (((hid >> 12) & 1) << 8) | (((hid >> 8) & 15) << 4) | ((hid >> 4) & 3)
-u = np.unique(key)
-ends = np.array([end[key == k].max() for k in u]) / 100.0
-print("SIMDs", len(u), "SIMD finish time us p0/10/50/90/99/100:", q(ends))
+key = (xcc << 20) | (((hid >> 13) & 7) << 12) | (((hid >> 12) & 1) << 8) | (((hid >> 8) & 15) << 4) | ((hid >> 4) & 3)   # one value per SIMD
+u, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+fin = np.zeros(len(u)); np.maximum.at(fin, inv, end / 100.0)
+cost = (wave[:, 6] & 0xFFFF).astype(np.float64) + 5 * (wave[:, 6] >> 16)
+csum = np.zeros(len(u)); np.add.at(csum, inv, cost)
+print("SIMDs", len(u), "waves per SIMD histogram:", np.bincount(cnt).tolist())
+print("SIMD finish time us p0/10/50/90/99/100:", q(fin))
+print("SIMD cost sum (trips + 5 * batches):", q(csum), " corr(finish, cost sum) = %.2f" % np.corrcoef(fin, csum)[0, 1])
 p.close()
