@@ -1000,13 +1000,18 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
     const size_t est = (size_t)p->ctr_host[C_BLOCKS] + (size_t)p->ctr_host[C_BLOCKS] / 8 + 2048;
     const size_t wgs = std::min<size_t>(std::max<size_t>((est + 3) / 4, 2048), 65536);
     const dim3 grid(p->integ_grid > 0 ? (unsigned)p->integ_grid : (unsigned)wgs);
-    if (sdf) {
-      if (p->stats) hipLaunchKernelGGL((k_integrate<false, true>), grid, block, 0, p->stream, m, p->depth, a);
-      else hipLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, p->stream, m, p->depth, a);
-    } else {
-      if (p->stats) hipLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, p->stream, m, p->depth, a);
-      else hipLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, p->stream, m, p->depth, a);
+#define SE_SWEEP(OF, ST, SHD) hipLaunchKernelGGL((k_integrate<OF, ST, SHD>), grid, block, 0, p->stream, m, p->depth, a)
+    switch ((sdf ? 0 : 4) | (p->stats ? 2 : 0) | (a.shard_world > 1 ? 1 : 0)) {
+      case 0: SE_SWEEP(false, false, false); break;
+      case 1: SE_SWEEP(false, false, true); break;
+      case 2: SE_SWEEP(false, true, false); break;
+      case 3: SE_SWEEP(false, true, true); break;
+      case 4: SE_SWEEP(true, false, false); break;
+      case 5: SE_SWEEP(true, false, true); break;
+      case 6: SE_SWEEP(true, true, false); break;
+      case 7: SE_SWEEP(true, true, true); break;
     }
+#undef SE_SWEEP
   }
   // the next frame's scan / depth upload may start behind this point: an event for the scan stream to wait on, or (host
   // gate) the sequence number of the raycast that follows

@@ -645,7 +645,9 @@ __device__ __forceinline__ void se_update_node_corner(const DevMap& m, const flo
 // (lane = 4 consecutive x of the rows (y, z) and (y, z+4): the per-row projection twice per lane instead of 8 times,
 // 7 % fewer VALU instructions, 101 VGPRs instead of 91) 28.2 / 135.8 / 877 us against 27.7 / 130.6 / 852 us at
 // 512^3 / 1024^3 / 2048^3 -- the sweep is bound by neither instruction count nor load width.
-template <bool OFUSION, bool STATS>
+// SHARD: the owner-computes variant (IntegArgs::shard_world > 1) -- a template parameter because its packing code costs the
+// plain sweep 11 VGPRs (91 -> 102: 4 waves per SIMD instead of 5, 128 -> 138 us at 1024^3).
+template <bool OFUSION, bool STATS, bool SHARD>
 __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * SE_WG + threadIdx.x) >> 6;
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   for (uint32_t b = wave; b < nblocks; b += nwaves) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
-    if (a.shard_world > 1 && (unsigned)((bx >> 3) + (by >> 3) + (bz >> 3)) % (unsigned)a.shard_world != (unsigned)a.shard_rank) continue;
+    if (SHARD && (unsigned)((bx >> 3) + (by >> 3) + (bz >> 3)) % (unsigned)a.shard_world != (unsigned)a.shard_rank) continue;
     const uint32_t slot = block_slot(m, b, bp);
     if (!m.bactive[slot] && !se_in_frustum(a, bx, by, bz)) continue;
     if (STATS && lane == 0) ++swept;
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     }
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
-    if (a.shard_world > 1) {   // the other replicas get this block's flag and, if anything of it was in view, its voxels
+    if (SHARD) {   // the other replicas get this block's flag and, if anything of it was in view, its voxels
       // record slots are handed out by SE_SHARD_SUB counters, each over its own 1/SE_SHARD_SUB of the segment (one
       // counter for the ~10 k blocks of a frame is 50-70 us of serialised atomics: one word takes ~90 of them per us)
       const uint32_t sub = (uint32_t)wave & (SE_SHARD_SUB - 1), subcap = a.shard_cap / SE_SHARD_SUB;
