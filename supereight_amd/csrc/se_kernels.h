@@ -663,8 +663,12 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
   if (a.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_count = 0ull;
   if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x, 64u));   // nothing in this kernel reads occ[]; the raycast that follows does
   __shared__ unsigned s_hist[768];
-  if (a.prio_thr && blockIdx.x == 0) se_ray_schedule(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille, a.ray_order);
-  for (uint32_t b = wave; b < nblocks; b += nwaves) {
+  // workgroup 0 computes the next raycast's schedule (a serial 256-step scan in the middle: ~10 us) and therefore takes no
+  // blocks -- with its share of them on top it was the last workgroup of the launch to finish
+  const bool scheduler = a.prio_thr != nullptr && gridDim.x > 1;
+  const int wskip = scheduler ? SE_WG / 64 : 0;
+  if (scheduler && blockIdx.x == 0) se_ray_schedule(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille, a.ray_order);
+  for (uint32_t b = (scheduler && blockIdx.x == 0) ? nblocks : (uint32_t)(wave - wskip); b < nblocks; b += (uint32_t)(nwaves - wskip)) {
     const uint32_t bp = m.bpos[b];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
     if (SHARD && (unsigned)((bx >> 3) + (by >> 3) + (bz >> 3)) % (unsigned)a.shard_world != (unsigned)a.shard_rank) continue;
