@@ -1,0 +1,54 @@
+"""The raycast's scheduling state (previous-frame tile costs -> issue priorities, cost-sorted deal of the workgroups'
+tile pairs over the compute units) must never reach the results: the same frames with the deal in image order
+(SE_HIP_RAY_DEAL=1), without the cost feedback at all (SE_HIP_PRIO=0) and with the defaults give the same map and the
+same vertex / normal images, bit for bit -- on an image whose tile count is odd (21 x 15 tiles: the last workgroup has one
+tile, the pairs wrap around the row ends) -- and those equal the oracle's."""
+import numpy as np
+import pytest
+
+from oracle.binding import SDF, OraclePipeline
+from supereight_amd.pipeline import DenseSLAMPipeline
+from supereight_amd.synthetic import SyntheticStream, to_colmajor
+from tests.parity_util import compare_maps, compare_raycast
+
+pytestmark = pytest.mark.gpu
+
+W, H, N, DIM, MU, FRAMES = 168, 116, 256, 2.4, 0.1, 9
+
+
+def _run(monkeypatch, env):
+    import torch
+    for k in ("SE_HIP_RAY_DEAL", "SE_HIP_PRIO"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = SyntheticStream(W, H, DIM)
+    depths = [s.depth(f) for f in range(FRAMES)]
+    poses = [s.pose(f) for f in range(FRAMES)]
+    dev = torch.from_numpy(np.stack(depths)).cuda()
+    p = DenseSLAMPipeline((W, H), N, DIM, field_type=SDF)     # the knobs are read once, here
+    k = np.ascontiguousarray(s.k, np.float32)
+    for f in range(FRAMES):
+        p.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, MU, f)
+    v, n = p.vertex_normal()
+    return p, v, n, depths, poses, s.k
+
+
+def test_schedule_never_changes_results(monkeypatch):
+    ref, v0, n0, depths, poses, k = _run(monkeypatch, {})
+    assert (n0[..., 0] != -2).sum() > 5000
+    for env in ({"SE_HIP_RAY_DEAL": "1"}, {"SE_HIP_PRIO": "0"}, {"SE_HIP_RAY_DEAL": "7"}):
+        p, v, n, _, _, _ = _run(monkeypatch, env)
+        assert (v.view(np.uint32) == v0.view(np.uint32)).all() and (n.view(np.uint32) == n0.view(np.uint32)).all(), env
+        c0, x0, y0, a0 = ref.blocks(); c, x, y, a = p.blocks()
+        assert (c == c0).all() and (x.view(np.uint32) == x0.view(np.uint32)).all() and (y.view(np.uint32) == y0.view(np.uint32)).all() and (a == a0).all(), env
+        p.close()
+    cpu = OraclePipeline(SDF, N, DIM, W, H)
+    for f in range(FRAMES):
+        cpu.integrate(depths[f], poses[f], k, MU, f)
+        _, v_c, n_c = cpu.raycast(poses[f], k, MU, f)
+    m = compare_maps(cpu, ref)
+    assert m["same_block_set"] and m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0, m
+    r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": v0, "n_g": n0}, DIM / N)
+    assert r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, r
+    cpu.close(); ref.close()
