@@ -130,7 +130,7 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose[16], const float
  * (projective_functor.hpp:139-160) above; measured and priced in DESIGN.md section 7, off by default.  Replica `rank` of
  * `world` updates only the blocks it owns (owner = (bx + by + bz) mod world, block units) and packs, for each of them, its
  * position, its new active flag and -- if any voxel was in view -- its 512 voxels into the caller's send segment of
- * se_hip_sweep_shard_bytes(cap_bricks) bytes, cap_bricks a multiple of 64: [u64 counts x 64][u32 records x cap][float vx
+ * se_hip_sweep_shard_bytes(cap_bricks) bytes (16-byte aligned), cap_bricks a multiple of 64: [u64 counts x 64][u32 records x cap][float vx
  * x 512 x cap][float vy x 512 x cap], counter c over the records [c * cap / 64, (c + 1) * cap / 64).  After the caller's all-gather of the segments (rank order), se_hip_apply_bricks writes the other replicas'
  * records into this replica's map on the main stream; se_hip_brick_exchange issues that all-gather itself
  * (se_hip_set_exchange) on the main stream and then applies.  A segment that overflows makes the next stage call fail with

@@ -896,8 +896,8 @@ size_t se_hip_sweep_shard_bytes(size_t cap_bricks) { return SE_SHARD_SUB * 8 + c
 int se_hip_set_sweep_shard(se_hip_pipeline* p, int32_t rank, int32_t world, void* send_device, size_t cap_bricks) {
   if (int r = check(p)) return r;
   if (world <= 1) { p->shard_world = 0; p->shard_send = nullptr; p->shard_cap = 0; return SE_HIP_OK; }
-  if (rank < 0 || rank >= world || !send_device || cap_bricks == 0 || (cap_bricks % SE_SHARD_SUB) || cap_bricks > ((size_t)1 << 30))
-    return fail(SE_HIP_E_INVALID, "bad argument (cap_bricks must be a positive multiple of 64)");
+  if (rank < 0 || rank >= world || !send_device || ((uintptr_t)send_device & 15u) || cap_bricks == 0 || (cap_bricks % SE_SHARD_SUB) || cap_bricks > ((size_t)1 << 30))
+    return fail(SE_HIP_E_INVALID, "bad argument (send segment 16-byte aligned, cap_bricks a positive multiple of 64)");
   p->shard_world = world; p->shard_rank = rank; p->shard_send = (unsigned char*)send_device; p->shard_cap = cap_bricks;
   return SE_HIP_OK;
 }
