@@ -964,6 +964,28 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   mul3(a.R, vs3, a.delta);                           // projective_functor.hpp:76-77
   mul3(a.K3, a.delta, a.cdelta);
   a.mu = mu;
+#ifdef SE_FAST_DIV_MU
+  if (sdf) {
+    // one binade of numerators, exhaustively, for this divisor (the three operations are homogeneous under scaling by powers
+    // of two): ~0.1-0.4 s the first time a mu is seen
+    static float checked_mu = 0.f, checked_inv = 0.f;
+    if (mu != checked_mu) {
+      checked_mu = mu; checked_inv = 0.f;
+      if (mu > 0x1p-60f && mu < 0x1p60f) {
+        const float r = (float)(1.0 / (double)mu);
+        bool ok = true;
+        for (uint32_t m23 = 0; m23 < (1u << 23) && ok; ++m23) {
+          const uint32_t u = 0x3F800000u | m23;
+          float x; std::memcpy(&x, &u, 4);
+          const float q0 = x * r, rem = std::fmaf(-q0, mu, x), q = std::fmaf(rem, r, q0), ref = x / mu;
+          ok = std::memcmp(&q, &ref, 4) == 0;
+        }
+        if (ok) checked_inv = r;
+      }
+    }
+    a.inv_mu = checked_inv;
+  }
+#endif
   a.maxweight = 100.f;                               // DenseSLAMSystem.cpp:235
   a.timestamp = (1.f / 30.f) * frame;                // DenseSLAMSystem.cpp:243
   a.W = p->cfg.width; a.H = p->cfg.height;

@@ -411,6 +411,9 @@ struct IntegArgs {
   float cdelta[3];         // K3 * delta
   float voxel;
   float mu;                // SDF: mu; OFusion: noiseFactor
+#ifdef SE_FAST_DIV_MU
+  float inv_mu;            // RN(1 / mu) if the 3-instruction quotient has been verified for this mu, else 0 (se_sdf_apply_nb)
+#endif
   float maxweight;
   float timestamp;         // OFusion
   int W, H;
@@ -527,10 +530,30 @@ __device__ __forceinline__ int se_bspline_index(float t) {
 // (results of lanes that the reference skips are discarded by the final selects), so that the 8
 // z-slices of a lane are 8 independent dependency chains the compiler can interleave -- the sweep is
 // bound by the latency of the IEEE division / square-root sequences, not by their count.
+template <bool FASTMU = false>
 __device__ __forceinline__ bool se_sdf_apply_nb(const IntegArgs& a, bool valid, float depthSample, f3 pos, float& vx, float& vy) {
   const float diff = (depthSample - pos.z) * sqrtf(1 + sqf(pos.x / pos.z) + sqf(pos.y / pos.z));
   const bool upd = valid && !(depthSample <= 0) && (diff > -a.mu);
+#ifdef SE_FAST_DIV_MU
+  // Experiment (off in the product build; tools/lemmas/div_exact.c): diff / mu with the correctly rounded
+  // reciprocal r of the run-time constant divisor -- q0 = diff * r, the exact residual, one correction: 3 instructions
+  // instead of the 11 of the IEEE sequence, and the IEEE quotient for every 2^-100 <= |diff| <= 2^100 (the host has checked
+  // one whole binade of numerators for THIS mu before it hands over inv_mu != 0).  Outside that range the result cannot
+  // differ where it is used: diff is +0 (both give +0), or >= 2^-38 in magnitude (a difference of depths >= 1e-4 m, times a
+  // factor >= 1), and for diff > 2^100 both quotients are >= 1 or NaN, which fminf(1, .) turns into 1; negative diff of
+  // that size fails `diff > -mu`.
+  float quot;
+  if (FASTMU) {
+    const float q0 = diff * a.inv_mu;
+    const float rem = __builtin_fmaf(-q0, a.mu, diff);
+    quot = __builtin_fmaf(rem, a.inv_mu, q0);
+  } else {
+    quot = diff / a.mu;
+  }
+  const float sdf = fminf(1.f, quot);
+#else
   const float sdf = fminf(1.f, diff / a.mu);
+#endif
   const float nx = clampf((vy * vx + sdf) / (vy + 1.f), -1.f, 1.f);
   const float ny = fminf(vy + 1, a.maxweight);
   vx = upd ? nx : vx;
@@ -720,9 +743,17 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) ds[zi] = depthmap[pidx[zi]];
     bool upd[8];
+#ifdef SE_FAST_DIV_MU
+    if (!OFUSION && a.inv_mu != 0.f) {
 #pragma unroll
-    for (int zi = 0; zi < 8; ++zi)
-      upd[zi] = OFUSION ? se_bfusion_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]) : se_sdf_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
+      for (int zi = 0; zi < 8; ++zi) upd[zi] = se_sdf_apply_nb<true>(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
+    } else
+#endif
+    {
+#pragma unroll
+      for (int zi = 0; zi < 8; ++zi)
+        upd[zi] = OFUSION ? se_bfusion_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]) : se_sdf_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
+    }
     // a voxel the functor left alone is written back unchanged only if a neighbour in the same 256-byte
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
 #pragma unroll
