@@ -429,7 +429,6 @@ bool stage_runs_integration(uint32_t frame, uint32_t rate) { return ((frame % ra
 // at initValue().  Enqueued on the main stream.
 void reset_map_state(se_hip_pipeline* p) {
   DevMap& m = p->map;
-  const size_t cells = (size_t)1 << (3 * p->leaf_level);
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
