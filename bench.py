@@ -294,7 +294,7 @@ def main():
     os.environ.setdefault("OMP_PLACES", "cores")
     import torch
     import torch.distributed as dist
-    from supereight_amd.multi_gpu import ShardedPipeline, row_partition
+    from supereight_amd.multi_gpu import ShardedPipeline
     from supereight_amd.pipeline import OFUSION, SDF, DenseSLAMPipeline
     from supereight_amd.synthetic import SyntheticStream
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle.binding import OFUSION, SDF
-from supereight_amd.multi_gpu import BIG_FRAMES, row_partition
+from supereight_amd.multi_gpu import row_partition
 from supereight_amd.pipeline import DenseSLAMPipeline
 from supereight_amd.synthetic import SyntheticStream
 

@@ -5,8 +5,6 @@ reference's Octree::save layout (octree.hpp:898-914) with exactly those records.
 import os
 import subprocess
 
-import numpy as np
-
 from supereight_amd.mapio import load_octree
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

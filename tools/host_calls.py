@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from supereight_amd.pipeline import DenseSLAMPipeline, SDF
-from supereight_amd.synthetic import SyntheticStream, to_colmajor
+from supereight_amd.synthetic import SyntheticStream
 W, H, N, dim, mu, F = 640, 480, 512, 4.8, 0.1, 210
 s = SyntheticStream(W, H, dim)
 depth = torch.from_numpy(np.stack([s.depth(f) for f in range(F)])).cuda()

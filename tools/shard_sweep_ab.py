@@ -5,7 +5,6 @@ import json
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from supereight_amd.multi_gpu import row_partition
 from supereight_amd.pipeline import DenseSLAMPipeline, SDF, OFUSION

@@ -24,7 +24,6 @@ print("gap sweep->ray mean %.2f  ray->sweep mean %.2f  frame period mean %.2f" %
 scans = [x for x in tail if x[2] == "scan"]
 sw = [x for x in tail if x[2] == "sweep"]
 # scan end relative to the raycast end of the same period, and sweep start relative to scan end
-import bisect
 rays = [x for x in tail if x[2] == "ray"]
 d1 = []; d2 = []
 for sc in scans:
