@@ -18,7 +18,15 @@
  *   - k = (fx, fy, cx, cy) as Eigen::Vector4f k in the reference API.
  *   - one handle <-> one caller thread at a time (the reference is not re-entrant either).
  *   - all work is enqueued on one HIP stream per handle; calls that return data to the host
- *     synchronise that stream, the others are asynchronous.
+ *     synchronise that stream, the others are asynchronous -- with one exception (the "host gate", dense unsharded
+ *     handles): se_hip_alloc_scan / se_hip_integrate / se_hip_frame and the depth uploads wait on the HOST until the
+ *     raycast behind the previous integration sweep has started on the device (normally less than a frame period; after
+ *     20 ms of wall clock the wait turns into hipStreamSynchronize of the handle's stream).  A caller that hands in its own
+ *     stream (se_hip_set_stream) must therefore not hold that stream behind work it has not enqueued yet.  SE_HIP_HOST_GATE=0
+ *     in the environment selects the event-ordered form, in which no stage call waits on the host.
+ *   - SE_HIP_E_CAPACITY is sticky: once a pool, key list or brick segment has overflowed, every later stage call and
+ *     se_hip_sync return it (the map / the replicas are no longer what the reference would hold) until se_hip_load_map
+ *     re-initialises the map or the caller acknowledges it with se_hip_clear_overflow().
  */
 #ifndef SE_HIP_H
 #define SE_HIP_H
@@ -68,6 +76,10 @@ const char* se_hip_last_error(void);
 /* free function synchroniseDevices() is declared but never defined in the reference
  * (se_denseslam/include/se/DenseSLAMSystem.h:418); this is its body. */
 int se_hip_sync(se_hip_pipeline* p);
+/* Acknowledges a reported SE_HIP_E_CAPACITY (see the conventions above): synchronises, clears the device-side overflow flag and
+ * returns the code that was pending (0 = none, 1 = block / node pool, 2 = key list, 3 = brick segment).  The map keeps whatever
+ * it lost; the call only lets a caller that has dealt with that (e.g. by reloading the map) carry on. */
+int se_hip_clear_overflow(se_hip_pipeline* p);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the handle's own. */
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
 /* The stream the allocation scan (se_hip_alloc_scan) is launched on when it overlaps the previous
@@ -75,8 +87,12 @@ int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
  * all-gather of the key lists is ordered on, so that scan + exchange of frame f+1 hide behind the
  * raycast of frame f.  NULL = a stream owned by the handle (the default). */
 int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
-/* 1 if se_hip_alloc_scan runs on the scan stream (dense replicas, overlap on), 0 if it runs on the main stream like
- * every other stage -- in which case work ordered with the scan (an all-gather of its list) belongs on the main stream. */
+/* 1 if the key list of se_hip_alloc_scan is produced on the scan stream (dense replicas, overlap on), 0 if on the main
+ * stream like every other stage -- in which case work ordered with the scan (an all-gather of its list) belongs on the main
+ * stream.  With overlap on, a handle that is row-sharded, writes its list into a caller buffer (se_hip_set_new_keys_buffer)
+ * or has an exchange set (se_hip_set_exchange) ALWAYS scans on the scan stream; only a plain single handle whose main
+ * stream is idle at the call (a caller that synchronises every frame) gets the scan straight onto the main stream, and
+ * nobody else consumes its list.  se_hip_alloc_exchange / se_hip_alloc_commit follow the stream the last scan ran on. */
 int se_hip_scan_overlaps(se_hip_pipeline* p);
 
 /* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by

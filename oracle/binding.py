@@ -133,7 +133,7 @@ def load(native: bool = False, fma: bool = False):
 
 
 SDF, OFUSION = 0, 1
-STAT_NAMES = ("probes", "keys_emitted", "swept", "nodes", "gets", "interps", "grads", "hits", "oob", "truncated")
+STAT_NAMES = ("probes", "keys_emitted", "swept", "nodes", "gets", "interps", "grads", "hits", "oob", "truncated", "oob_ub")
 
 
 class OraclePipeline:
@@ -239,7 +239,7 @@ class OraclePipeline:
         return code, side, x, y
 
     def stats(self) -> dict:
-        out = np.zeros(10, np.uint64)
+        out = np.zeros(11, np.uint64)
         self.lib.so_pipe_stats(self.h, out)
         return dict(zip(STAT_NAMES, (int(v) for v in out)))
 

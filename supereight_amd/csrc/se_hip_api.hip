@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -58,6 +60,26 @@ void mul3(const float r[9], const float v[3], float out[3]) {
 
 struct TimedLaunch { int kernel; hipEvent_t start, stop; };
 
+// spin-wait hint, portable (the host side must also build on aarch64 hosts)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
+// Polls `done()` for at most `limit_us` of wall-clock time (checked every 256 polls); false = gave up.
+template <typename F> bool spin_until(F done, long long limit_us) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned n = 1;; ++n) {
+    if (done()) return true;
+    cpu_relax();
+    if ((n & 255u) == 0u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > limit_us) return done();
+  }
+}
+
 }  // namespace
 
 struct se_hip_pipeline {
@@ -80,6 +102,7 @@ struct se_hip_pipeline {
   bool gate_followed = false;      // ... and a raycast was enqueued behind it
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
+  bool scan_on_side = false;   // stream the LAST allocation scan ran on: se_hip_alloc_exchange / se_hip_alloc_commit follow it
   bool upload_on_side = false; // the current depth image was uploaded on `side`
   const float* scaled0 = nullptr;   // scaled_depth_[0] of the last se_hip_track
   // direct RCCL exchange of the key lists (se_hip_set_exchange): the caller's communicator and ncclAllGather
@@ -342,6 +365,7 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.stack_depth = p->leaf_level;
   a.tile_cost = p->prio_hint ? p->tile_cost : nullptr;
   a.prio_thr = p->prio_thr;
+  a.cost_shift = std::max(0, p->leaf_level - 6);
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
@@ -358,11 +382,11 @@ void wait_last_sweep(se_hip_pipeline* p) {
   if (!p->gate_armed) return;
   p->gate_armed = false;
   if (p->gate_followed) {
+    // a frame period normally (the raycast behind the sweep starts within tens of microseconds); 20 ms of wall clock at most,
+    // then the ordinary stream synchronisation -- e.g. when the caller's stream is held behind work of its own
     volatile uint32_t* w = p->gate_host;
-    for (unsigned long long spins = 0; (int32_t)(*w - p->gate_target) < 0; ++spins) {
-      if (spins > 400000000ull) { hipStreamSynchronize(p->stream); return; }   // (seconds: something is very slow; be safe)
-      __builtin_ia32_pause();
-    }
+    const uint32_t target = p->gate_target;
+    if (!spin_until([&] { return (int32_t)(*w - target) >= 0; }, 20000)) hipStreamSynchronize(p->stream);
     return;
   }
   hipStreamSynchronize(p->stream);
@@ -643,6 +667,20 @@ int se_hip_sync(se_hip_pipeline* p) {
   return check_overflow(p);
 }
 
+int se_hip_clear_overflow(se_hip_pipeline* p) {
+  if (int r = check(p)) return r;
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->gate_armed = false;
+  uint32_t dev = 0;
+  HIP_TRY(hipMemcpy(&dev, p->map.ctr + C_OVERFLOW, sizeof dev, hipMemcpyDeviceToHost));
+  const uint32_t pending = std::max(dev, p->ctr_host[C_OVERFLOW]);
+  HIP_TRY(hipMemsetAsync(p->map.ctr + C_OVERFLOW, 0, sizeof(uint32_t), p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->ctr_host[C_OVERFLOW] = 0u;
+  return (int)pending;
+}
+
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream) {
   if (int r = check(p)) return r;
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -767,7 +805,11 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   // depends on this frame's raycast) finds the main stream idle here, and the scan then goes straight onto it -- no
   // cross-stream events between scan and sweep (closed loop 110 -> 9x us per frame).  Row-sharded replicas keep the scan
   // stream: their all-gather is ordered on it.
-  const bool ov = p->overlap && (p->sharded || hipStreamQuery(p->stream) == hipErrorNotReady);
+  // ... and so do handles whose key list is a caller buffer or goes into an exchange (se_hip_set_new_keys_buffer,
+  // se_hip_set_exchange): whoever consumes that list is told "scan stream" by se_hip_scan_overlaps().
+  const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
+  const bool ov = p->overlap && (p->sharded || caller_list || p->xgather != nullptr || hipStreamQuery(p->stream) == hipErrorNotReady);
+  p->scan_on_side = ov;
   hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
   ms.defer_occ = ov ? 1 : 0;
@@ -843,7 +885,7 @@ int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
   const unsigned long long* lists = (const unsigned long long*)device_lists;
-  if (p->overlap && p->side) {
+  if (p->overlap && p->side && p->scan_on_side) {
     // The gathered lists were produced on the scan stream (scan kernel, then the caller's all-gather ordered
     // behind it).  The insertion of the peers' keys stays on that stream -- beside the previous frame's raycast,
     // off the sweep -> raycast critical path -- and, like the scan, leaves occ[] to the sweep kernel, which
@@ -884,7 +926,7 @@ int se_hip_alloc_exchange(se_hip_pipeline* p, uint64_t* recv_device, int64_t wor
   if (!p->xgather) return fail(SE_HIP_E_INVALID, "no exchange set (se_hip_set_exchange)");
   if (!recv_device || words < 2 || (unsigned long long)words > p->map.cap_keys + 1) return fail(SE_HIP_E_INVALID, "bad argument");
   // on the stream the scan ran on: behind the scan, beside the previous frame's raycast
-  hipStream_t s = (p->overlap && p->side) ? p->side : p->stream;
+  hipStream_t s = (p->overlap && p->side && p->scan_on_side) ? p->side : p->stream;
   const int rc = p->xgather(p->map.newkeys, recv_device, (size_t)words, /* ncclInt64 */ 4, p->xcomm, s);
   if (rc != 0) return fail(SE_HIP_E_DEVICE, "ncclAllGather failed with code " + std::to_string(rc));
   return se_hip_alloc_commit(p, recv_device, p->xworld, words);
@@ -1194,12 +1236,10 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
       const unsigned seq = ++p->reduce_seq;
       hipLaunchKernelGGL(k_track_reduce_final, dim3(1), dim3(32), 0, s, p->reduce_out, p->reduce_partial, p->reduce_host, (unsigned*)seq_word, seq);
       HIP_TRY(hipGetLastError());
-      {   // wait for the sums to land in pinned memory (bounded: fall back to a stream synchronisation after ~50 ms)
-        unsigned long long spins = 0;
-        while (*seq_word != seq) {
-          if (++spins > 50000000ull) { HIP_TRY(hipStreamSynchronize(s)); if (*seq_word != seq) return fail(SE_HIP_E_DEVICE, "tracking reduction did not complete"); break; }
-          __builtin_ia32_pause();
-        }
+      // wait for the sums to land in pinned memory (bounded: 50 ms of wall clock, then a stream synchronisation)
+      if (!spin_until([&] { return *seq_word == seq; }, 50000)) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (*seq_word != seq) return fail(SE_HIP_E_DEVICE, "tracking reduction did not complete");
       }
       ++done;
       float x[6];
@@ -1571,11 +1611,18 @@ int se_hip_load_map(se_hip_pipeline* p, const char* filename) {
   }
   std::fclose(f);
   if (!okr) return fail(SE_HIP_E_INVALID, "truncated or malformed map file");
-  // quiesce, re-initialise, insert
-  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  p->scan_pending = false; p->occ_commit_due = false; p->occ_lists = OccLists{nullptr, 0, 0};
-  reset_map_state(p);
+  // node keys straight from the file: level and position must be those of an internal node of THIS tree
+  for (unsigned long long kx : keys) {
+    const int level = (int)(kx & 0x1FFull);
+    if (level == 0 && kx != 0ull) return fail(SE_HIP_E_INVALID, "malformed map file (node key)");
+    if (level == 0) continue;
+    if (level >= p->leaf_level) return fail(SE_HIP_E_INVALID, "malformed map file (node level)");
+    const unsigned long long code = kx & ~0x1FFull;
+    const int sh = p->max_level - level;
+    const unsigned long long lim = 1ull << level;
+    if ((se_compact21(code) >> sh) >= lim || (se_compact21(code >> 1) >> sh) >= lim || (se_compact21(code >> 2) >> sh) >= lim)
+      return fail(SE_HIP_E_INVALID, "malformed map file (node position)");
+  }
   std::vector<unsigned long long> list;
   list.reserve(1 + keys.size() + bkeys.size());
   list.push_back(0ull);
@@ -1588,6 +1635,11 @@ int se_hip_load_map(se_hip_pipeline* p, const char* filename) {
   const size_t nval = std::max((size_t)nb * 512, (size_t)nn * 8) + 8;
   if (hipMalloc((void**)&d_list, list.size() * 8) != hipSuccess || hipMalloc((void**)&d_x, nval * 4) != hipSuccess || hipMalloc((void**)&d_y, nval * 4) != hipSuccess ||
       hipMalloc((void**)&d_c, ((size_t)nb * 3 + 4) * 4) != hipSuccess || hipMalloc((void**)&d_k, ((size_t)nn + 1) * 8) != hipSuccess) { cleanup(); return fail(SE_HIP_E_DEVICE, "hipMalloc (load staging)"); }
+  // everything that can fail without touching the map has succeeded: quiesce, re-initialise, insert
+  if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->scan_pending = false; p->occ_commit_due = false; p->occ_lists = OccLists{nullptr, 0, 0};
+  reset_map_state(p);
   hipMemcpyAsync(d_list, list.data(), list.size() * 8, hipMemcpyHostToDevice, p->stream);
   hipLaunchKernelGGL(k_alloc_commit, dim3(256, 1), dim3(SE_WG), 0, p->stream, p->map, d_list, 1, (long long)list.size());
   if (nn) {

@@ -808,6 +808,9 @@ __global__ __launch_bounds__(SE_WG) void k_apply_bricks(DevMap m, const unsigned
   // wave w walks sub-segment w mod SE_SHARD_SUB (the grid has a multiple of SE_SHARD_SUB waves)
   const uint32_t sub = wave & (SE_SHARD_SUB - 1);
   const uint32_t n = (uint32_t)min(counts[sub], (unsigned long long)subcap);
+  // the sender ran out of record slots: it raised its own C_OVERFLOW, and so does every receiver of the truncated segment --
+  // all replicas report SE_HIP_E_CAPACITY for the same frame instead of the sender alone
+  if (counts[sub] > (unsigned long long)subcap && lane == 0 && wave < SE_SHARD_SUB) m.ctr[C_OVERFLOW] = 3u;
   for (uint32_t j = wave / SE_SHARD_SUB; j < n; j += nwaves / SE_SHARD_SUB) {
     const uint32_t i = sub * subcap + j;
     const uint32_t r = recs[i], bp = r & 0x3FFFFFFFu;
@@ -866,6 +869,8 @@ struct RayArgs {
   uint32_t* gate;
   uint32_t gate_seq;
   unsigned short* tile_cost;
+  int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
+                       // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
 #ifdef SE_DIAG
   int debug_phases;    // diagnostic build only: bit0 = skip march + gradient, bit1 = skip gradient, bit2 = skip the traversal (results are then wrong)
@@ -1468,7 +1473,8 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   const int tile_slot = __builtin_amdgcn_readfirstlane(tile_in_image ? ty * tiles_x + tx : 0);
   unsigned my_cost = 0u;
   if (a.tile_cost) {
-    const int prev = __builtin_amdgcn_readfirstlane((int)a.tile_cost[tile_slot]);
+    // (clamped like the histogram bins the thresholds come from; 256 = "no tile gets this priority")
+    const int prev = min(__builtin_amdgcn_readfirstlane((int)a.tile_cost[tile_slot]), 255);
     if (prev >= a.prio_thr[2]) __builtin_amdgcn_s_setprio(3);
     else if (prev >= a.prio_thr[1]) __builtin_amdgcn_s_setprio(2);
     else if (prev >= a.prio_thr[0]) __builtin_amdgcn_s_setprio(1);
@@ -1534,7 +1540,7 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
     uint32_t* slot = s_par + (threadIdx.x & ~63);
     if (lane == 0) *slot = 0u;
     atomicMax(slot, my_cost);
-    if (lane == 0 && tile_in_image) a.tile_cost[tile_slot] = (unsigned short)min(*slot, 65535u);
+    if (lane == 0 && tile_in_image) a.tile_cost[tile_slot] = (unsigned short)min(*slot >> a.cost_shift, 65535u);
   }
 #ifdef SE_DIAG
   const bool quiet = a.diag_wave != nullptr;   // per-wave records only: the contended stats atomics would distort the clocks
@@ -1594,6 +1600,7 @@ __global__ __launch_bounds__(SE_WG) void k_load_nodes(DevMap m, const unsigned l
       const unsigned long long code = key & ~0x1FFull;
       const int sh = m.max_level - level;
       const int px = (int)(se_compact21(code) >> sh), py = (int)(se_compact21(code >> 1) >> sh), pz = (int)(se_compact21(code >> 2) >> sh);
+      if ((unsigned)px >= (1u << level) || (unsigned)py >= (1u << level) || (unsigned)pz >= (1u << level)) continue;   // (k_alloc_commit skipped it too)
       const uint32_t e = m.tab[tab_index(m, level, px, py, pz)];
       if (e == 0u || e == SE_PENDING) continue;
       nid = e - 1u;

@@ -40,6 +40,7 @@ EXPORTS = {
     "se_hip_destroy": (C.c_int, [C.c_void_p]),
     "se_hip_last_error": (C.c_char_p, []),
     "se_hip_sync": (C.c_int, [C.c_void_p]),
+    "se_hip_clear_overflow": (C.c_int, [C.c_void_p]),
     "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_scan_overlaps": (C.c_int, [C.c_void_p]),
@@ -188,6 +189,10 @@ class DenseSLAMPipeline:
 
     def sync(self):
         self._check(self.lib.se_hip_sync(self._h))
+
+    def clear_overflow(self) -> int:
+        """Acknowledge a sticky SE_HIP_E_CAPACITY; returns the pending code (0 none, 1 pool, 2 key list, 3 brick segment)."""
+        return self._check(self.lib.se_hip_clear_overflow(self._h))
 
     def set_stream(self, hip_stream_ptr: int):
         self._check(self.lib.se_hip_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

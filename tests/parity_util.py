@@ -6,11 +6,11 @@ import numpy as np
 
 from oracle.binding import OraclePipeline
 from supereight_amd.pipeline import DenseSLAMPipeline
-from supereight_amd.synthetic import SyntheticStream
+from supereight_amd.synthetic import make_stream
 
 
-def run_both(field, W, H, N, dim, mu, frames, holes=True, max_blocks=0, on_frame=None, negative_fy=False):
-    stream = SyntheticStream(W, H, dim, holes=holes, negative_fy=negative_fy)
+def run_both(field, W, H, N, dim, mu, frames, holes=True, max_blocks=0, on_frame=None, negative_fy=False, stream_kind="room"):
+    stream = make_stream(stream_kind, W, H, dim, holes=holes, negative_fy=negative_fy) if stream_kind == "room" else make_stream(stream_kind, W, H, dim, holes=holes)
     cpu = OraclePipeline(field, N, dim, W, H)
     gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field, max_blocks=max_blocks)
     cpu.count_stats(True)

@@ -92,3 +92,73 @@ def test_surface_statistics_match_the_reference_run():
     assert abs(1e3 * d.mean() / 0.98 - 1) < 0.01
     assert abs(1e3 * np.percentile(d, 99) / 3.6 - 1) < 0.02
     gpu.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Breadth.  SURVEY 8(d)'s tolerances were measured on 6 noise-free frames of the box-room stream.
+# On longer sequences (weights saturate, rounding differences accumulate), at 1024^3, and on the ICL-like stress stream
+# (sensor noise, clipped surfaces, fast motion) the reference's OWN two build flavours -- the same restatement compiled
+# -ffp-contract=off and -ffp-contract=fast (+ Sophus quaternion round trip) -- sit further apart than those figures
+# (measured on the CPU alone, profiles/r03_asbuilt_cpu_floor.log: e.g. 60 frames at 512^3: |dTSDF| > 1e-5 on 4.9e-4 of the
+# voxels; stress stream, 40 frames: vertex error <= 0.5 voxel on 98.6 % instead of 99 %).  The claim that can be gated
+# everywhere is therefore relative: the HIP path is no further from the as-built reference than the contraction-off build of
+# the reference itself is -- metric by metric, on the same frames -- and where SURVEY's absolute figures do hold for the
+# two CPU builds, they hold for the HIP path too.  Distributions go to gpurun_out/asbuilt_<name>.json (README publishes them).
+# ------------------------------------------------------------------------------------------------------------------
+BREADTH = [
+    # name, field, stream, N, mu, frames
+    ("room_sdf_1024_6f", SDF, "room", 1024, 0.1, 6),
+    ("room_sdf_512_60f", SDF, "room", 512, 0.1, 60),
+    ("stress_sdf_512_40f", SDF, "stress", 512, 0.1, 40),
+    ("stress_ofusion_512_30f", OFUSION, "stress", 512, 0.008, 30),
+]
+LOWER_IS_BETTER = ("block_set_symdiff_frac", "x_gt_1e6_frac", "x_gt_1e5_frac", "x_gt_1e3_frac", "y_differs_frac", "hitmask_disagree_frac",
+                   "vert_err_vox_p90", "vert_err_vox_p99", "vert_err_vox_p999", "normal_deg_p99", "normal_deg_p999")
+HIGHER_IS_BETTER = ("vert_le_0p1_vox_frac", "vert_le_0p5_vox_frac", "vert_le_2_vox_frac")
+
+
+@pytest.mark.parametrize("name,field,kind,N,mu,frames", BREADTH, ids=[b[0] for b in BREADTH])
+def test_asbuilt_distance_within_the_references_own_build_spread(name, field, kind, N, mu, frames):
+    from supereight_amd.synthetic import make_stream, stress_surface_distance
+    lib = load(fma=True)
+    assert lib.so_fp_contract() == 1
+    lib.so_set_sophus_quat(1)
+    try:
+        fma = OraclePipeline(field, N, DIM, W, H, fma=True)     # the reference as its authors build it
+        off = OraclePipeline(field, N, DIM, W, H)               # the reference built with contraction off (the parity target)
+        gpu = DenseSLAMPipeline((W, H), N, DIM, field_type=field)
+        s = make_stream(kind, W, H, DIM)
+        for f in range(frames):
+            d, pose = s.depth(f), s.pose(f)
+            gpu.set_depth(d); gpu.setPose(pose)
+            gpu.integration(s.k, 1, mu, f); gpu.raycasting(s.k, mu, f)
+            fma.integrate(d, pose, s.k, mu, f); off.integrate(d, pose, s.k, mu, f)
+            _, v_f, n_f = fma.raycast(pose, s.k, mu, f)
+            _, v_o, n_o = off.raycast(pose, s.k, mu, f)
+        v_g, n_g = gpu.vertex_normal()
+        rel = field == OFUSION
+        fb = fma.blocks()
+        hip = dict(map=map_distance(gpu.blocks(), fb, relative_x=rel), raycast=raycast_distance(v_g, n_g, v_f, n_f, DIM / N))
+        cpu = dict(map=map_distance(off.blocks(), fb, relative_x=rel), raycast=raycast_distance(v_o, n_o, v_f, n_f, DIM / N))
+        sd = stress_surface_distance if kind == "stress" else surface_distance
+        for tag, v, n in (("hip", v_g, n_g), ("off", v_o, n_o), ("asbuilt", v_f, n_f)):
+            ds = sd(v[n[..., 0] != -2], DIM)
+            hip["raycast"]["surface_mm_" + tag] = {"mean": 1e3 * float(ds.mean()), "p99": 1e3 * float(np.percentile(ds, 99))}
+        report = {"config": f"{W}x{H} -> {N}^3, {kind} stream, {'SDF' if field == SDF else 'OFusion'} mu={mu}, {frames} frames",
+                  "hip_vs_asbuilt": hip, "contraction_off_build_vs_asbuilt": cpu,
+                  "survey_tolerances_missed_by_the_two_cpu_builds": check_survey_tolerances(cpu["map"], cpu["raycast"]),
+                  "survey_tolerances_missed_by_hip": check_survey_tolerances(hip["map"], hip["raycast"])}
+        print(json.dumps(report))
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/asbuilt_{name}.json", "w") as fh:
+            json.dump(report, fh, indent=1)
+        both = {**hip["map"], **hip["raycast"]}, {**cpu["map"], **cpu["raycast"]}
+        for key in LOWER_IS_BETTER:
+            assert both[0][key] <= both[1][key] * 1.0001 + 1e-12, (key, both[0][key], both[1][key])
+        for key in HIGHER_IS_BETTER:
+            assert both[0][key] >= both[1][key] * 0.9999, (key, both[0][key], both[1][key])
+        assert set(k for k, _ in report["survey_tolerances_missed_by_hip"]) <= set(k for k, _ in report["survey_tolerances_missed_by_the_two_cpu_builds"])
+        assert hip["map"]["block_set_symdiff_frac"] <= 1e-3
+        fma.close(); off.close(); gpu.close()
+    finally:
+        lib.so_set_sophus_quat(0)

@@ -262,3 +262,67 @@ def test_create_replicas_partitions_the_image_rows():
     assert lib.se_hip_create_replicas(C.byref(cfg), ids20, 20, h20) < 0 and all(not h for h in h20)
     for p in reps:
         p.close()
+
+
+def test_unsharded_handle_with_caller_key_list_orders_commit_behind_scan():
+    """a handle that covers the whole image but writes its key list into a caller buffer (a one-rank
+    exchange, or a C caller of se_hip_new_keys_device + se_hip_alloc_commit) and synchronises every frame found its main
+    stream idle, so the scan went onto the main stream while exchange / commit stayed on the scan stream -- unordered.
+    The scan of such a handle now always runs on the scan stream and commit / exchange follow the stream the scan used.
+    Result must be the plain pipeline's, bit for bit, and the consumer of the list must see a complete list."""
+    import torch
+    W, H, N, dim, mu, frames = 160, 120, 256, 2.4, 0.1, 7
+    stream = SyntheticStream(W, H, dim)
+    single = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+    p = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+    assert p.scan_overlaps()
+    words = 1 << 15
+    send = torch.zeros(words, dtype=torch.int64, device="cuda")
+    p.set_new_keys_buffer(send.data_ptr(), words, keepalive=send)
+    total_keys = 0
+    for f in range(frames):
+        depth, pose = stream.depth(f), stream.pose(f)
+        for q in (single, p):
+            q.set_depth(depth); q.setPose(pose)
+        before = single.counts()[0]
+        single.integration(stream.k, 1, mu, f); single.raycasting(stream.k, mu, f); single.sync()
+        p.sync()                                      # main stream idle: the situation of the finding
+        assert p.alloc_scan(stream.k, 1, mu, f)
+        p.alloc_commit(send.data_ptr(), 1, words)     # no sync in between: ordered by the library
+        p.integrate_sweep(stream.k, 1, mu, f)
+        p.raycasting(stream.k, mu, f)
+        p.sync()
+        n_keys = int(send[0].item())
+        new_blocks = single.counts()[0] - before
+        keys = send[1:1 + n_keys].cpu().numpy().view(np.uint64)
+        assert int(((keys >> np.uint64(63)) == 0).sum()) >= new_blocks   # the list holds (at least) every new block of the frame
+        total_keys += n_keys
+    assert total_keys > 500
+    c, x, y, a = single.blocks()
+    rc, rx, ry, ra = p.blocks()
+    assert rc.shape == c.shape and (rc == c).all() and (ra == a).all()
+    assert (rx.view(np.uint32) == x.view(np.uint32)).all() and (ry.view(np.uint32) == y.view(np.uint32)).all()
+    v, n = single.vertex_normal(); rv, rn = p.vertex_normal()
+    assert (rv.view(np.uint32) == v.view(np.uint32)).all() and (rn.view(np.uint32) == n.view(np.uint32)).all()
+    single.close(); p.close()
+
+
+def test_capacity_error_is_sticky_until_cleared():
+    """SE_HIP_E_CAPACITY stays raised on every later stage call and on sync (se_hip.h conventions) until the caller
+    acknowledges it with se_hip_clear_overflow, which names what overflowed."""
+    from supereight_amd.pipeline import SeHipError
+    W, H, N, dim, mu = 160, 120, 256, 2.4, 0.1
+    stream = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim, field_type=SDF, max_blocks=256)     # frame 0 needs ~2000 blocks
+    with pytest.raises(SeHipError, match="pool exhausted"):
+        for f in range(3):
+            p.set_depth(stream.depth(f)); p.setPose(stream.pose(f))
+            p.integration(stream.k, 1, mu, f)
+            p.sync()
+    with pytest.raises(SeHipError, match="pool exhausted"):
+        p.sync()                                     # sticky
+    assert p.clear_overflow() == 1
+    p.sync()                                         # acknowledged
+    assert p.clear_overflow() == 0
+    assert p.counts()[0] == 256                      # the pool is full, its counter stayed bounded
+    p.close()
