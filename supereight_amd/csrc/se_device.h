@@ -28,6 +28,12 @@
 #include <stdint.h>
 
 #define SE_PENDING 0xFFFFFFFFu
+// Floats from one brick to the next in a voxel plane.  512: vx[] and vy[] are two separate arrays (r01-r02).  1024: one array of
+// 4 KB bricks [512 x | 512 y] and vy = vx + 512 -- a voxel's two values share a 4 KB page (one address translation per get()
+// instead of two; dense maps scatter bricks over 8 / 64 GiB), see DESIGN.md 3.
+#ifndef SE_BRICK_STRIDE
+#define SE_BRICK_STRIDE 512
+#endif
 #define SE_MAX_LEVELS 12
 
 enum { C_BLOCKS = 0, C_NODES = 1, C_OVERFLOW = 2, C_COUNT = 8 };

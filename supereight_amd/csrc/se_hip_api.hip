@@ -469,8 +469,12 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
   std::memset(p->ctr_host, 0, C_COUNT * sizeof(uint32_t));
   p->ctr_host[C_NODES] = 1u;
+#if SE_BRICK_STRIDE == 1024
+  hipLaunchKernelGGL(k_fill_bricks, dim3(16384), dim3(256), 0, p->stream, m.vx, m.init_x, m.init_y, p->slots * 1024);
+#else
   hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vx, m.init_x, p->slots * 512);
   hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vy, m.init_y, p->slots * 512);
+#endif
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.nx, m.init_x, p->cap_nodes * 8);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.ny, m.init_y, p->cap_nodes * 8);
 }
@@ -569,8 +573,13 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   }
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
+#if SE_BRICK_STRIDE == 1024
+  ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
+  m.vy = m.vx + 512;
+#else
   ALLOC(m.vx, slots * 512 * sizeof(float));
   ALLOC(m.vy, slots * 512 * sizeof(float));
+#endif
   ALLOC(m.bpos, cap * sizeof(uint32_t));
   ALLOC(m.bactive, (slots + 3) & ~(size_t)3);   // whole 32-bit words: se_set_active_once
   ALLOC(m.nx, capn * 8 * sizeof(float));
@@ -636,7 +645,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.tab, m.vx, m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
+  void* ptrs[] = {m.occ, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);

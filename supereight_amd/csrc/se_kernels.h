@@ -698,8 +698,8 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     const uint32_t slot = block_slot(m, b, bp);
     if (!m.bactive[slot] && !se_in_frustum(a, bx, by, bz)) continue;
     if (STATS && lane == 0) ++swept;
-    float* px = m.vx + (size_t)slot * 512 + lane;
-    float* py = m.vy + (size_t)slot * 512 + lane;
+    float* px = m.vx + (size_t)slot * SE_BRICK_STRIDE + lane;
+    float* py = m.vy + (size_t)slot * SE_BRICK_STRIDE + lane;
     float vx[8], vy[8];
 #ifdef SE_DIAG
     if (a.debug == 2) {
@@ -822,8 +822,8 @@ __global__ __launch_bounds__(SE_WG) void k_apply_bricks(DevMap m, const unsigned
     if (r >> 31) {
       const float* sx = bvx + (size_t)i * 512 + lane;
       const float* sy = bvy + (size_t)i * 512 + lane;
-      float* dx = m.vx + (size_t)slot * 512 + lane;
-      float* dy = m.vy + (size_t)slot * 512 + lane;
+      float* dx = m.vx + (size_t)slot * SE_BRICK_STRIDE + lane;
+      float* dy = m.vy + (size_t)slot * SE_BRICK_STRIDE + lane;
 #pragma unroll
       for (int zi = 0; zi < 8; ++zi) { dx[zi * 64] = sx[zi * 64]; dy[zi * 64] = sy[zi * 64]; }
     }
@@ -908,7 +908,7 @@ __device__ __forceinline__ uint32_t se_block_of(const DevMap& m, int x, int y, i
   return e;
 }
 __device__ __forceinline__ size_t se_voxel_index(uint32_t e, int x, int y, int z) {
-  return (size_t)(e - 1u) * 512 + (size_t)((x & 7) + ((y & 7) << 3) + ((z & 7) << 6));
+  return (size_t)(e - 1u) * SE_BRICK_STRIDE + (size_t)((x & 7) + ((y & 7) << 3) + ((z & 7) << 6));
 }
 
 // Memory-level parallelism is what the raycast kernel lives on: a wave is a chain of dependent L2
@@ -975,7 +975,7 @@ __device__ __forceinline__ AxisTerm se_axis_x(int x) { return {(uint32_t)(x >> 3
 __device__ __forceinline__ AxisTerm se_axis_y(const DevMap& m, int y) { return {(uint32_t)(y >> 3) << m.leaf_level, (uint32_t)(y & 7) << 3}; }
 __device__ __forceinline__ AxisTerm se_axis_z(const DevMap& m, int z) { return {(uint32_t)(z >> 3) << (2 * m.leaf_level), (uint32_t)(z & 7) << 6}; }
 __device__ __forceinline__ size_t se_axis_index(AxisTerm a, AxisTerm b, AxisTerm c) {
-  return ((size_t)(a.blk + b.blk + c.blk) << 9) + (size_t)(a.loc + b.loc + c.loc);
+  return (size_t)(a.blk + b.blk + c.blk) * SE_BRICK_STRIDE + (size_t)(a.loc + b.loc + c.loc);
 }
 
 // Dense grid: the address of every corner of an interpolation cell follows from the position alone, so
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
 // map read-back: packs the bricks named by slots[] (already in the caller's order) contiguously
 __global__ __launch_bounds__(SE_WG) void k_gather_bricks(const float* __restrict__ plane, const uint32_t* __restrict__ slots, size_t n, float* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 512; i += (size_t)gridDim.x * SE_WG)
-    out[i] = plane[(size_t)slots[i >> 9] * 512 + (i & 511)];
+    out[i] = plane[(size_t)slots[i >> 9] * SE_BRICK_STRIDE + (i & 511)];
 }
 // se_hip_load_map: values of the octants of a map file -> device planes (the octants were inserted by k_alloc_commit before)
 __global__ __launch_bounds__(SE_WG) void k_load_nodes(DevMap m, const unsigned long long* __restrict__ keys, const float* __restrict__ x, const float* __restrict__ y, size_t n) {
@@ -1615,11 +1615,15 @@ __global__ __launch_bounds__(SE_WG) void k_load_blocks(DevMap m, const int* __re
     const int bx = coords[3 * b] >> 3, by = coords[3 * b + 1] >> 3, bz = coords[3 * b + 2] >> 3;
     const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
     if (e == 0u || e == SE_PENDING) continue;
-    m.vx[(size_t)(e - 1u) * 512 + (i & 511)] = x[i];
-    m.vy[(size_t)(e - 1u) * 512 + (i & 511)] = y[i];
+    m.vx[(size_t)(e - 1u) * SE_BRICK_STRIDE + (i & 511)] = x[i];
+    m.vy[(size_t)(e - 1u) * SE_BRICK_STRIDE + (i & 511)] = y[i];
   }
 }
 // pool initialisation: every voxel / node value starts at voxel_traits<T>::initValue()
+// both planes of interleaved bricks ([512 x][512 y] per brick): n = floats in total
+__global__ void k_fill_bricks(float* __restrict__ p, float vx, float vy, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (i & 512) ? vy : vx;
+}
 __global__ void k_fill(float* __restrict__ p, float v, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -16,6 +16,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 if [ "$WHAT" = full ]; then
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -o $TAG -- $BENCH > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $OUT/pmc_cache -o $TAG -- $BENCH > /dev/null 2> $OUT/pmc_cache.err
+# address translation + memory latency (r03): dense bricks are scattered over 1 / 8 / 64 GiB
+rocprofv3 --kernel-trace --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_TCC_READ_REQ_LATENCY_sum --output-format csv -d $OUT/pmc_tlb -o $TAG -- $BENCH > /dev/null 2> $OUT/pmc_tlb.err
+rocprofv3 --kernel-trace --pmc TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lat -o $TAG -- $BENCH > /dev/null 2> $OUT/pmc_lat.err
 fi
 python tools/summarize_prof.py $OUT $TAG > $OUT/summary.md 2> $OUT/summary.err
 cat $OUT/summary.md; tail -3 $OUT/summary.err

@@ -55,7 +55,7 @@ if trace:
             continue
         print(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.2f} | {d[len(d) // 2] / 1e3:.2f} | {d[int(len(d) * 0.95)] / 1e3:.2f} |")
     print()
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_cache"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_cache", "pmc_tlb", "pmc_lat"):
     files = find(sub, "*counter_collection.csv")
     if not files:
         continue
