@@ -563,7 +563,9 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   hipEventCreateWithFlags(&p->ev_sweep, hipEventDisableTiming | hipEventDisableSystemFence);
   hipEventCreateWithFlags(&p->ev_scan, hipEventDisableTiming | hipEventDisableSystemFence);
   p->sharded = (p->row_begin != 0 || p->row_end != cfg->height);
-  p->overlap = dense && !std::getenv("SE_HIP_NO_OVERLAP");
+  // r03: pooled bricks overlap too (their raycast reads the index the scan writes: see se_block_entry for why that race is
+  // benign); SE_HIP_POOLED_OVERLAP=0 restores the serial schedule for pooled maps
+  p->overlap = (dense || !(std::getenv("SE_HIP_POOLED_OVERLAP") && std::atoi(std::getenv("SE_HIP_POOLED_OVERLAP")) == 0)) && !std::getenv("SE_HIP_NO_OVERLAP");
   p->host_gate = p->overlap && !p->sharded;
   if (const char* ev = std::getenv("SE_HIP_HOST_GATE")) p->host_gate = p->host_gate && std::atoi(ev) != 0;   // tuning knob
   if (p->host_gate) {
@@ -841,12 +843,9 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
-#if SE_SCAN_TILED
-      const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
+      // a wave covers 8 x (8 / SE_SCAN_SPLIT) pixels, SE_SCAN_SPLIT lanes per pixel (k_alloc_scan_sdf)
+      const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 8 / SE_SCAN_SPLIT - 1) / (8 / SE_SCAN_SPLIT));
       const dim3 sgrid((tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
-#else
-      const dim3 sgrid = grid;
-#endif
       if (m.dense) {
         if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, true>), sgrid, block, 0, s, ms, p->depth, a);
         else hipLaunchKernelGGL((k_alloc_scan_sdf<false, true>), sgrid, block, 0, s, ms, p->depth, a);

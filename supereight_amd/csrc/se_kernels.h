@@ -24,6 +24,9 @@
 #ifndef SE_SPEC
 #define SE_SPEC 2     // SDF march: samples fetched per memory round trip (measured 1 / 2 / 3 / 4: 51.3 / 50.3 / 50.0 / 51.6 us at 512^3, 81 / 77 / 78 / 82 us at 1024^3)
 #endif
+#ifndef SE_SPEC_DEEP
+#define SE_SPEC_DEEP 8  // SDF march through unobserved space (last sample had weight 0): samples per round trip (<= SE_SPEC: off)
+#endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
 
 // ------------------------------------------------------------------------------------------
@@ -129,9 +132,6 @@ struct AllocArgs {
 #ifndef SE_SCAN_SLOTS
 #define SE_SCAN_SLOTS 8     // distinct blocks of one ray buffered before their flags are fetched
 #endif
-#ifndef SE_SCAN_TILED
-#define SE_SCAN_TILED 1     // a wave scans an 8x8 pixel tile (its rays cross the same 1-2 blocks) instead of 64 pixels of a row
-#endif
 template <bool STATS, bool DENSE>
 __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& a, const uint32_t* s_blk, int nb, unsigned long long& newk) {
   const int L = m.leaf_level;
@@ -166,31 +166,35 @@ __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& 
     }
   }
 }
+// r03: (1) a step that stays in the block of the previous one is recognised by six float compares against that block's
+// bounds in voxel units (floor(s) in [8b, 8b+8) <=> s in [8b, 8b+8) for the integer bounds) -- the floor / range test /
+// float->int / shift sequence of the reference's loop body runs only when a step leaves the block (2-4 times per ray, and
+// for steps outside the volume); (2) SPLIT lanes share one pixel, lane j walking steps [j * chunk, (j + 1) * chunk) after
+// j * chunk bare additions voxelPos += step (the positions are defined by that accumulation, so they are replayed, not
+// computed from i * step): the launch is one round of resident waves whose duration is the length of one lane's dependent
+// chain, and that chain is what SPLIT shortens.  Block set, active flags and key list (as a set) are unchanged.
+#ifndef SE_SCAN_SPLIT
+#define SE_SCAN_SPLIT 1
+#endif
 template <bool STATS, bool DENSE>
 __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
   __shared__ uint32_t s_blk_all[SE_SCAN_SLOTS * SE_WG_SCAN];
   uint32_t* s_blk = s_blk_all + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
-  int x, y;
+  constexpr int SPLIT = SE_SCAN_SPLIT;
+  constexpr int PXW = 8, PXH = 8 / SPLIT;          // pixels of one wave: 8 x 8, 8 x 4 or 8 x 2
+  int x, y, part;
   bool in_image;
-#if SE_SCAN_TILED
   {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
-    const int tiles_x = (a.W + 7) >> 3;
-    x = (tile % tiles_x) * 8 + (lane & 7);
-    y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
+    const int tiles_x = (a.W + PXW - 1) / PXW;
+    part = lane / (PXW * PXH);
+    const int pl = lane % (PXW * PXH);
+    x = (tile % tiles_x) * PXW + (pl % PXW);
+    y = a.row_begin + (tile / tiles_x) * PXH + (pl / PXW);
     in_image = x < a.W && y < a.row_end;
   }
-#else
-  {
-    const int npix = (a.row_end - a.row_begin) * a.W;
-    const int pid = blockIdx.x * SE_WG_SCAN + threadIdx.x;
-    x = pid % a.W;
-    y = a.row_begin + pid / a.W;
-    in_image = pid < npix;
-  }
-#endif
   if (in_image) {
     const float depth = depthmap[x + y * a.W];
     if (!(depth == 0)) {
@@ -201,19 +205,34 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
       const f3 step = f3_div(f3_scale_r(direction, a.band), (float)a.num_steps);
       f3 voxelPos = origin;
       const float fsize = (float)m.size;
+      const int chunk = (a.num_steps + SPLIT - 1) / SPLIT;
+      const int i0 = part * chunk, i1 = min(a.num_steps, i0 + chunk);
+      for (int i = 0; i < i0; ++i) voxelPos = f3_add(voxelPos, step);      // replay of the accumulation up to this lane's first step
       uint32_t last = 0xFFFFFFFFu;   // last block recorded (probing it again changes nothing)
+      bool have = false;             // the previous step was inside the volume, in the block with these lower bounds (voxel units; upper = lower + 8)
+      float lox = 0.f, loy = 0.f, loz = 0.f;
       int nb = 0;
-      for (int i = 0; i < a.num_steps; ++i) {
+      for (int i = i0; i < i1; ++i) {
         const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
-        const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
-        if ((vx < fsize) && (vy < fsize) && (vz < fsize) && (vx >= 0) && (vy >= 0) && (vz >= 0)) {
+        const bool same = have && (s.x >= lox) && (s.x < lox + 8.f) && (s.y >= loy) && (s.y < loy + 8.f) && (s.z >= loz) && (s.z < loz + 8.f);
+        if (same) {
           ++probes;
-          const uint32_t lin = block_linear(m, (int)vx >> 3, (int)vy >> 3, (int)vz >> 3);
-          if (lin != last) {
-            last = lin;
-            if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
-            s_blk[nb * SE_WG_SCAN] = lin;
-            ++nb;
+        } else {
+          const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
+          if ((vx < fsize) && (vy < fsize) && (vz < fsize) && (vx >= 0) && (vy >= 0) && (vz >= 0)) {
+            ++probes;
+            const int bx = (int)vx >> 3, by = (int)vy >> 3, bz = (int)vz >> 3;
+            const uint32_t lin = block_linear(m, bx, by, bz);
+            lox = (float)(bx << 3); loy = (float)(by << 3); loz = (float)(bz << 3);
+            have = true;
+            if (lin != last) {
+              last = lin;
+              if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
+              s_blk[nb * SE_WG_SCAN] = lin;
+              ++nb;
+            }
+          } else {
+            have = false;
           }
         }
         voxelPos = f3_add(voxelPos, step);
@@ -903,7 +922,8 @@ __device__ __forceinline__ uint32_t se_block_of(const DevMap& m, int x, int y, i
   const int bx = x >> 3, by = y >> 3, bz = z >> 3;
   if (DENSE) return block_linear(m, bx, by, bz) + 1u;
   if (bx == c.bx && by == c.by && bz == c.bz) return c.e;
-  const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
+  uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
+  e = e == SE_PENDING ? 0u : e;   // (see se_block_entry)
   c.bx = bx; c.by = by; c.bz = bz; c.e = e;
   return e;
 }
@@ -925,7 +945,11 @@ __device__ __forceinline__ uint32_t se_block_entry(const DevMap& m, int bx, int 
   if (DENSE) return ((unsigned)bx < (unsigned)nb && (unsigned)by < (unsigned)nb && (unsigned)bz < (unsigned)nb) ? block_linear(m, bx, by, bz) + 1u : 0u;
   if (bx == hint.bx && by == hint.by && bz == hint.bz) e = hint.e;
   else if ((unsigned)bx < (unsigned)nb && (unsigned)by < (unsigned)nb && (unsigned)bz < (unsigned)nb) e = m.tab[leaf_index(m, bx, by, bz)];
-  return e;
+  // Pooled bricks: the allocation scan of the NEXT frame may be inserting blocks while this raycast runs (overlap mode).  An
+  // entry in flight reads as PENDING -> "not allocated"; one already published points at a brick that still holds
+  // initValue() in every voxel (bricks are pre-filled and never recycled), which is exactly what "not allocated" reads as
+  // (initValue().x == empty().x for both field types) -- so the race cannot change a result.
+  return e == SE_PENDING ? 0u : e;
 }
 
 // Octree::interp (octree.hpp:541-563) with gather_points (interp_gather.hpp:107-237): every corner
@@ -1302,11 +1326,19 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
           // formed by the same float additions the sequential loop performs.
           float S = a.largestep;
           bool done = false;
+          // `deep`: the last sample consumed read weight 0 (unobserved space, almost always an unallocated block), so the march is
+          // walking in largesteps and will keep doing so until it reaches the next surface band -- the longest dependent chains of
+          // a launch are such walks behind silhouettes and depth edges (tools/march_policy.py: 34 round trips for the slowest ray
+          // of a 1024^3 frame, 17 with 8 samples per round trip there).  SE_SPEC_DEEP samples ride on one round trip in that state;
+          // everywhere else a batch stays SE_SPEC samples (every extra sample is ~25 VALU instructions the bulk of the rays would
+          // pay for nothing: uniform batches of 4 measured slower).
+          bool deep = false;
           for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
             ++rc.n_batch;
+            constexpr int NS = SE_SPEC_DEEP > SE_SPEC ? SE_SPEC_DEEP : SE_SPEC;
             f3 q[SE_SPEC];
             uint32_t qe[SE_SPEC];
-            float qx[SE_SPEC], qy[SE_SPEC];
+            float qx[NS], qy[NS];
             int qi[SE_SPEC][3];
             q[0] = position;
 #pragma unroll
@@ -1322,6 +1354,23 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
               const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
               qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
             }
+            uint32_t qvalid = 0u;   // bit i: sample i lies inside the volume (and, pooled bricks, in an allocated block)
+#pragma unroll
+            for (int i = 0; i < SE_SPEC; ++i) qvalid |= qe[i] ? (1u << i) : 0u;
+            const int depth = (SE_SPEC_DEEP > SE_SPEC && deep) ? SE_SPEC_DEEP : SE_SPEC;
+            if (SE_SPEC_DEEP > SE_SPEC && deep) {
+              // positions by the same float additions the sequential loop performs (position += largestep * dir)
+              f3 qq = q[SE_SPEC - 1];
+#pragma unroll
+              for (int i = SE_SPEC; i < NS; ++i) {
+                qq = f3_add(qq, f3_scale(S, dir));
+                const int ix = cvt_i32(a.inv_voxel * qq.x), iy = cvt_i32(a.inv_voxel * qq.y), iz = cvt_i32(a.inv_voxel * qq.z);
+                const uint32_t e = in_volume(m, ix, iy, iz) ? se_block_entry<DENSE>(m, ix >> 3, iy >> 3, iz >> 3, c) : 0u;
+                const size_t vi = e ? se_voxel_index(e, ix, iy, iz) : 0;
+                qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
+                qvalid |= e ? (1u << i) : 0u;
+              }
+            }
             // Near the surface every step changes the step size, so a batch ends after its first sample
             // and that sample usually wants the interpolated value: on the dense grid its 8 corners ride
             // along with the gets instead of costing a round trip of their own.
@@ -1334,10 +1383,13 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
               for (int k = 0; k < 8; ++k) cv0[k] = m.vx[vi0[k]];
             }
 #pragma unroll
-            for (int i = 0; i < SE_SPEC; ++i) {
+            for (int i = 0; i < NS; ++i) {
+              if (i >= depth) break;
               if (!(t < tfar)) { done = true; break; }
               if (STATS) ++n_get;
-              const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
+              const bool ok = (qvalid >> i) & 1u;
+              const float dx = ok ? qx[i] : fc.init_x, dy = ok ? qy[i] : fc.init_y;
+              deep = dy == 0;
               if (dy == 0) {
                 stepsize = a.largestep;
                 position = f3_add(position, f3_scale(stepsize, dir));
@@ -1347,7 +1399,8 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
                   if (DENSE && i == 0) {
                     f_tt = se_interp_blend(cell0, cv0);
                   } else {
-                    c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
+                    // (pooled bricks: the block of this sample as the look-up hint -- known for the samples of the regular batch)
+                    if (i < SE_SPEC) { c.bx = qi[i < SE_SPEC ? i : 0][0] >> 3; c.by = qi[i < SE_SPEC ? i : 0][1] >> 3; c.bz = qi[i < SE_SPEC ? i : 0][2] >> 3; c.e = qe[i < SE_SPEC ? i : 0]; }
                     f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
                   }
                   if (STATS) ++n_interp;

@@ -364,6 +364,15 @@ class DenseSLAMPipeline:
             self._check(self.lib.se_hip_download_blocks(self._h, coords.ctypes.data, x.ctypes.data, y.ctypes.data, act.ctypes.data))
         return coords, x, y, act
 
+    def block_flags(self):
+        """coords[n,3] and VoxelBlock::active_[n] of the allocated blocks (sorted by key) without the voxel planes."""
+        nb, _ = self.counts()
+        coords = np.zeros((nb, 3), np.int32)
+        act = np.zeros(nb, np.uint8)
+        if nb:
+            self._check(self.lib.se_hip_download_blocks(self._h, coords.ctypes.data, None, None, act.ctypes.data))
+        return coords, act
+
     def nodes(self):
         _, nn = self.counts()
         code = np.zeros(nn, np.uint64)
