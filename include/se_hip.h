@@ -156,6 +156,20 @@ int se_hip_set_sweep_shard(se_hip_pipeline* p, int32_t rank, int32_t world, void
 int se_hip_apply_bricks(se_hip_pipeline* p, const void* recv_device, int32_t world);
 int se_hip_brick_exchange(se_hip_pipeline* p, void* recv_device);
 
+/* Full vertex_ / normal_ images on every rank of a row-sharded run: se_hip_raycast of a sharded handle fills
+ * only the handle's own image rows, but their consumer -- tracking(), DenseSLAMSystem.cpp:175-177, and the render*() methods --
+ * reads the whole images.  A tile = the rows [row_begin, row_end) of a rank, padded to max_rows rows (the largest share of
+ * the partition), vertex rows first, then normal rows: se_hip_image_tile_bytes(p, max_rows) bytes.
+ *   se_hip_pack_image_tile    copies the handle's own rows of both images into send_device (one tile);
+ *   se_hip_apply_image_tiles  writes the other ranks' tiles (recv_device = world tiles in rank order, as an all-gather of the
+ *                             packed tiles delivers them; row_begin / row_end = the partition) into this handle's images;
+ *   se_hip_gather_images      pack + ncclAllGather on the communicator of se_hip_set_exchange + apply.
+ * Everything is enqueued on the main stream, behind the raycast. */
+size_t se_hip_image_tile_bytes(se_hip_pipeline* p, int32_t max_rows);
+int se_hip_pack_image_tile(se_hip_pipeline* p, void* send_device, int32_t max_rows);
+int se_hip_apply_image_tiles(se_hip_pipeline* p, const void* recv_device, int32_t world, int32_t max_rows, const int32_t* row_begin, const int32_t* row_end);
+int se_hip_gather_images(se_hip_pipeline* p, void* send_device, void* recv_device, int32_t max_rows, const int32_t* row_begin, const int32_t* row_end);
+
 /* One frame of the loop of se_apps/src/benchmark.cpp:148-167 in one call: hand-over of a device-resident float_depth_
  * (NULL = keep the current depth image), then integration(), then raycasting() with the same pose -- exactly
  * se_hip_set_depth_device + se_hip_integrate + se_hip_raycast.  Returns bit 0 = integration ran, bit 1 = raycasting ran. */

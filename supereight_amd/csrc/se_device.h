@@ -32,7 +32,7 @@
 // 4 KB bricks [512 x | 512 y] and vy = vx + 512 -- a voxel's two values share a 4 KB page (one address translation per get()
 // instead of two; dense maps scatter bricks over 8 / 64 GiB), see DESIGN.md 3.
 #ifndef SE_BRICK_STRIDE
-#define SE_BRICK_STRIDE 512
+#define SE_BRICK_STRIDE 1024
 #endif
 #define SE_MAX_LEVELS 12
 

@@ -1149,6 +1149,46 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   return 1;
 }
 
+// ---- the vertex_ / normal_ row tiles of the ranks -> full images on every rank
+size_t se_hip_image_tile_bytes(se_hip_pipeline* p, int32_t max_rows) {
+  if (!p || max_rows <= 0) return 0;
+  return (size_t)2 * (size_t)max_rows * (size_t)p->cfg.width * 3 * sizeof(float);
+}
+int se_hip_pack_image_tile(se_hip_pipeline* p, void* send_device, int32_t max_rows) {
+  if (int r = check(p)) return r;
+  const int rows = p->row_end - p->row_begin;
+  if (!send_device || max_rows < rows) return fail(SE_HIP_E_INVALID, "bad argument (max_rows smaller than this handle's row share)");
+  const size_t row_bytes = (size_t)p->cfg.width * 3 * sizeof(float);
+  char* dst = (char*)send_device;
+  HIP_TRY(hipMemcpyAsync(dst, (const char*)p->vertex + (size_t)p->row_begin * row_bytes, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(dst + (size_t)max_rows * row_bytes, (const char*)p->normal + (size_t)p->row_begin * row_bytes, (size_t)rows * row_bytes, hipMemcpyDeviceToDevice, p->stream));
+  return SE_HIP_OK;
+}
+int se_hip_apply_image_tiles(se_hip_pipeline* p, const void* recv_device, int32_t world, int32_t max_rows, const int32_t* row_begin, const int32_t* row_end) {
+  if (int r = check(p)) return r;
+  if (!recv_device || world < 1 || max_rows <= 0 || !row_begin || !row_end) return fail(SE_HIP_E_INVALID, "bad argument");
+  const size_t row_bytes = (size_t)p->cfg.width * 3 * sizeof(float);
+  const size_t tile = (size_t)2 * max_rows * row_bytes;
+  for (int r = 0; r < world; ++r) {
+    const int b = row_begin[r], e = row_end[r];
+    if (b < 0 || e > p->cfg.height || e < b || e - b > max_rows) return fail(SE_HIP_E_INVALID, "bad row partition");
+    if (b == p->row_begin && e == p->row_end) continue;    // the own rows are in place
+    if (e == b) continue;
+    const char* src = (const char*)recv_device + (size_t)r * tile;
+    HIP_TRY(hipMemcpyAsync((char*)p->vertex + (size_t)b * row_bytes, src, (size_t)(e - b) * row_bytes, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync((char*)p->normal + (size_t)b * row_bytes, src + (size_t)max_rows * row_bytes, (size_t)(e - b) * row_bytes, hipMemcpyDeviceToDevice, p->stream));
+  }
+  return SE_HIP_OK;
+}
+int se_hip_gather_images(se_hip_pipeline* p, void* send_device, void* recv_device, int32_t max_rows, const int32_t* row_begin, const int32_t* row_end) {
+  if (int r = check(p)) return r;
+  if (!p->xgather) return fail(SE_HIP_E_INVALID, "no exchange set (se_hip_set_exchange)");
+  if (int r = se_hip_pack_image_tile(p, send_device, max_rows)) return r;
+  const int rc = p->xgather(send_device, recv_device, se_hip_image_tile_bytes(p, max_rows), /* ncclUint8 */ 1, p->xcomm, p->stream);
+  if (rc != 0) return fail(SE_HIP_E_DEVICE, "ncclAllGather failed with code " + std::to_string(rc));
+  return se_hip_apply_image_tiles(p, recv_device, p->xworld, max_rows, row_begin, row_end);
+}
+
 int se_hip_download_vertex_normal(se_hip_pipeline* p, float* v, float* n) {
   if (int r = check(p)) return r;
   const size_t bytes = (size_t)p->cfg.width * p->cfg.height * 3 * sizeof(float);

@@ -25,7 +25,11 @@
 #define SE_SPEC 2     // SDF march: samples fetched per memory round trip (measured 1 / 2 / 3 / 4: 51.3 / 50.3 / 50.0 / 51.6 us at 512^3, 81 / 77 / 78 / 82 us at 1024^3)
 #endif
 #ifndef SE_SPEC_DEEP
-#define SE_SPEC_DEEP 8  // SDF march through unobserved space (last sample had weight 0): samples per round trip (<= SE_SPEC: off)
+#define SE_SPEC_DEEP 0  // SDF march through unobserved space (last sample had weight 0): samples per round trip; <= SE_SPEC: off.
+                        // Built and measured in r03 (profiles/r03_ab1_interleave_deepspec.log): 8 samples cut the longest march from 34 to 17
+                        // round trips (tools/march_policy.py) and made the launch SLOWER, 40.5 -> 50.7 us at 512^3, 77 -> 83 us at 1024^3,
+                        // 248 -> 257 us at 2048^3 (4 samples: equal): the extra samples are ~30 VALU instructions and two cold lines each, for
+                        // every lane of a wave in which any lane is in that state, and half of them are fetched past the end of the walk.
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
 

@@ -48,6 +48,39 @@ def exchange_key_lists(local, world: int, group=None):
     return out
 
 
+def pack_row_tile(image, rows: Tuple[int, int], max_rows: int):
+    """The rows [rows[0], rows[1]) of an (H, W, C) image tensor as a (max_rows, W, C) tile, zero-padded: the fixed-size
+    message of the vertex / normal all-gather."""
+    import torch
+    tile = torch.zeros((max_rows,) + tuple(image.shape[1:]), dtype=image.dtype, device=image.device)
+    tile[: rows[1] - rows[0]] = image[rows[0]:rows[1]]
+    return tile
+
+
+def stitch_row_tiles(gathered, parts: List[Tuple[int, int]], out):
+    """Writes the tiles of an all-gather of pack_row_tile() messages (``gathered``: (world, max_rows, W, C)) into the
+    (H, W, C) image ``out`` according to the row partition; returns ``out``."""
+    for r, (b, e) in enumerate(parts):
+        out[b:e] = gathered[r, : e - b]
+    return out
+
+
+def gather_row_tiles(image, rows: Tuple[int, int], parts: List[Tuple[int, int]], group=None):
+    """Full (H, W, C) image on every rank from the ranks' row tiles, through torch.distributed (gloo on CPU tensors in the
+    tests; the RCCL path of ShardedPipeline.gather_images issues the collective from C instead)."""
+    import torch
+    import torch.distributed as dist
+    world = len(parts)
+    max_rows = max(e - b for b, e in parts)
+    tile = pack_row_tile(image, rows, max_rows)
+    recv = torch.empty(world * tile.numel(), dtype=tile.dtype, device=tile.device)      # flat, like the key lists
+    if world == 1:
+        recv.copy_(tile.reshape(-1))
+    else:
+        dist.all_gather_into_tensor(recv, tile.reshape(-1).contiguous(), group=group)
+    return stitch_row_tiles(recv.reshape((world,) + tuple(tile.shape)), parts, image.clone())
+
+
 def merged_keys(gathered, world: int) -> np.ndarray:
     """Host-side view of an exchanged buffer: the concatenation of all valid keys (uint64)."""
     g = gathered.detach().cpu().numpy().view(np.uint64).reshape(world, -1)
@@ -76,8 +109,12 @@ class ShardedPipeline:
         from .pipeline import DenseSLAMPipeline
         self.torch = torch
         self.rank, self.world, self.group = rank, world, group
-        rows = row_partition(int(input_size[1]), world)[rank]
+        self.parts = row_partition(int(input_size[1]), world)
+        rows = self.parts[rank]
         self.rows = rows
+        self.max_rows = max(e - b for b, e in self.parts)
+        self._img_send = self._img_recv = None
+        self._images_full = world == 1
         self.p = DenseSLAMPipeline(input_size, volume_resolution, volume_dimension, field_type=field_type,
                                    device=device, max_blocks=max_blocks, rows=rows)
         dev = torch.device("cuda", device)
@@ -146,6 +183,45 @@ class ShardedPipeline:
                 dist.all_gather_into_tensor(self.brecv, self.bsend, group=self.group)
         p.apply_bricks(self.brecv.data_ptr(), self.world)
 
+    def gather_images(self):
+        """after this call every rank holds the FULL vertex_ / normal_ images of the last raycast (each rank
+        raycasts its own rows only).  One all-gather of fixed-size row tiles on the main stream; a no-op for one rank and
+        when the images are already complete.  Needed by tracking() and the render methods, not by the integrate + raycast
+        loop itself, so it is only issued on demand."""
+        if self._images_full:
+            return
+        p, torch = self.p, self.torch
+        nbytes = p.image_tile_bytes(self.max_rows)
+        if self._img_send is None:
+            dev = self.send.device
+            self._img_send = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            self._img_recv = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
+        if self.direct:
+            p.gather_images(self._img_send.data_ptr(), self._img_recv.data_ptr(), self.parts, self.max_rows)
+        else:
+            p.pack_image_tile(self._img_send.data_ptr(), self.max_rows)
+            with torch.cuda.stream(self.main):
+                if self.gloo:
+                    import torch.distributed as dist
+                    host = self._img_send.cpu()
+                    out = torch.empty(self.world * host.numel(), dtype=host.dtype)
+                    dist.all_gather_into_tensor(out, host, group=self.group)
+                    self._img_recv.copy_(out)
+                elif self._pg is not None:
+                    self._pg._allgather_base(self._img_recv, self._img_send).wait()
+                else:
+                    import torch.distributed as dist
+                    dist.all_gather_into_tensor(self._img_recv, self._img_send, group=self.group)
+            p.apply_image_tiles(self._img_recv.data_ptr(), self.parts, self.max_rows)
+        self._images_full = True
+
+    def tracking(self, k, icp_threshold: float, tracking_rate: int, frame: int, pyramid=(10, 5, 4)) -> bool:
+        """DenseSLAMSystem::tracking in the sharded mode: the ICP reads the whole vertex_ / normal_ images of the last raycast,
+        so the row tiles are all-gathered first; every rank then runs the same (replicated, deterministic) tracker on the
+        full images and ends with the same pose, bit for bit."""
+        self.gather_images()
+        return self.p.tracking(k, icp_threshold, tracking_rate, frame, pyramid)
+
     def _direct_rccl(self, pg, dev) -> bool:
         """Hands the process group's ncclComm_t and the address of ncclAllGather (of the RCCL torch has loaded)
         to the C library, so that the per-frame exchange is one C call instead of a torch collective
@@ -200,6 +276,7 @@ class ShardedPipeline:
                     if self.shard_sweep:
                         self._exchange_bricks()
                     p.raycasting(k, mu, frame)
+                    self._images_full = self.world == 1
                     return ran
                 else:
                     if self._pg is not None:
@@ -213,6 +290,7 @@ class ShardedPipeline:
             if self.shard_sweep:
                 self._exchange_bricks()
         p.raycasting(k, mu, frame)
+        self._images_full = self.world == 1
         return ran
 
     def close(self):

@@ -60,6 +60,10 @@ EXPORTS = {
     "se_hip_apply_bricks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "se_hip_brick_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
+    "se_hip_image_tile_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
+    "se_hip_pack_image_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "se_hip_apply_image_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "se_hip_gather_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "se_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -363,6 +367,23 @@ class DenseSLAMPipeline:
         if nb:
             self._check(self.lib.se_hip_download_blocks(self._h, coords.ctypes.data, x.ctypes.data, y.ctypes.data, act.ctypes.data))
         return coords, x, y, act
+
+    # ---- full vertex_ / normal_ images on every rank of a row-sharded run (include/se_hip.h)
+    def image_tile_bytes(self, max_rows: int) -> int:
+        return int(self.lib.se_hip_image_tile_bytes(self._h, max_rows))
+
+    def pack_image_tile(self, send_ptr: int, max_rows: int):
+        self._check(self.lib.se_hip_pack_image_tile(self._h, C.c_void_p(send_ptr), max_rows))
+
+    def apply_image_tiles(self, recv_ptr: int, parts, max_rows: int):
+        b = np.ascontiguousarray([q[0] for q in parts], np.int32)
+        e = np.ascontiguousarray([q[1] for q in parts], np.int32)
+        self._check(self.lib.se_hip_apply_image_tiles(self._h, C.c_void_p(recv_ptr), len(parts), max_rows, b.ctypes.data, e.ctypes.data))
+
+    def gather_images(self, send_ptr: int, recv_ptr: int, parts, max_rows: int):
+        b = np.ascontiguousarray([q[0] for q in parts], np.int32)
+        e = np.ascontiguousarray([q[1] for q in parts], np.int32)
+        self._check(self.lib.se_hip_gather_images(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), max_rows, b.ctypes.data, e.ctypes.data))
 
     def block_flags(self):
         """coords[n,3] and VoxelBlock::active_[n] of the allocated blocks (sorted by key) without the voxel planes."""

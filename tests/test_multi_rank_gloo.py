@@ -139,3 +139,33 @@ def test_row_sharded_protocol_matches_unsharded_reference(field):
         assert (rx.view(np.uint32) == x.view(np.uint32)).all() and (ry.view(np.uint32) == y.view(np.uint32)).all()
         assert (ra == a).all()
         assert (rcode == code).all() and (rnx.view(np.uint32) == nx.view(np.uint32)).all() and (rny.view(np.uint32) == ny.view(np.uint32)).all()
+
+
+def _worker_tiles(rank, world, port, H, q):
+    _init(rank, world, port)
+    import torch
+    from supereight_amd.multi_gpu import gather_row_tiles, row_partition
+    W = 40
+    full = torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3)        # what the unsharded raycast would hold
+    parts = row_partition(H, world)
+    rows = parts[rank]
+    mine = torch.full((H, W, 3), -1.0)
+    mine[rows[0]:rows[1]] = full[rows[0]:rows[1]]                                # a rank's raycast fills its own rows only
+    out = gather_row_tiles(mine, rows, parts)
+    q.put((rank, bool(torch.equal(out, full)), [list(p) for p in parts]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [120, 116, 8])
+def test_vertex_normal_row_tiles_all_gather_world2(H):
+    """the ranks' raycast row tiles (unequal when the 8-row units do not divide by the world size; H = 8 leaves
+    rank 0 with no rows at all) -> the full image on every rank, through a real gloo all-gather of fixed-size padded tiles."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tiles, args=(r, 2, port, H, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(2)]
+    [p.join(60) for p in procs]
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2] and res[0][2][-1][1] == H
