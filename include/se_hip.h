@@ -185,9 +185,10 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, f
 
 /* ---- "next" row f-2: bool DenseSLAMSystem::tracking(const Vector4f& k, float icp_threshold,
  *      unsigned tracking_rate, unsigned frame)  (DenseSLAMSystem.h:173, DenseSLAMSystem.cpp:143-189):
- *      half-sample pyramid of the current depth image, depth2vertex / vertex2normal per level, ICP
- *      (trackKernel + reduceKernel on the device, updatePoseKernel's 6x6 solve + SE3 exp on the host)
- *      against vertex_ / normal_ of the last se_hip_raycast, checkPoseKernel.
+ *      half-sample pyramid of the current depth image, depth2vertex / vertex2normal per level, ICP against vertex_ /
+ *      normal_ of the last se_hip_raycast, checkPoseKernel.  The ICP loop is device-resident: one launch per iteration does
+ *      trackKernel + reduceKernel + updatePoseKernel (6x6 Cholesky solve, SE3 exponential, pose update, convergence test);
+ *      the call waits on the host once, for the final pose.
  *      pose_inout = pose_ (updated in place; restored if the check fails); pyramid = iterations per
  *      level, finest first (default {10, 5, 4}).  Returns 1 = tracked, 0 = gated off or rejected. */
 int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame,

@@ -93,6 +93,7 @@ struct se_hip_pipeline {
   bool own_side = false;       // false after se_hip_set_scan_stream handed one in
   hipEvent_t ev_sweep = nullptr, ev_scan = nullptr;
   bool overlap = false;
+  bool sync_spin = true;       // se_hip_sync polls before it blocks (SE_HIP_SYNC_SPIN=0: off)
   // host gate (see RayArgs::gate): replaces the event between the sweep and the next frame's scan for unsharded replicas
   bool host_gate = false;
   uint32_t* gate_host = nullptr;   // pinned word the raycast kernel writes its sequence number to
@@ -122,9 +123,9 @@ struct se_hip_pipeline {
   float raycast_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // column-major, pose of the last raycast
   std::vector<float*> pyr_depth, pyr_vertex, pyr_normal;  // level 0 depth aliases the current depth image
   TrackData* track = nullptr;
-  float* reduce_partial = nullptr;
-  float* reduce_out = nullptr;       // 8 x 32
-  float* reduce_host = nullptr;      // pinned, 8 x 32 (+ 1 word: sequence number of the last reduction that landed)
+  float* reduce_partial = nullptr;   // 8 x SE_TRACK_SEGMENTS x 32 partial sums of the running ICP iteration
+  IcpState* icp = nullptr;           // device: what one ICP iteration hands to the next
+  IcpHostRecord* icp_host = nullptr; // pinned: the one record the host reads per tracked frame
   unsigned reduce_seq = 0;
   int track_iterations = 0;
   unsigned char* rgbw = nullptr;   // render target (W*H*4)
@@ -252,70 +253,6 @@ int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlis
 }
 
 
-// ---- updatePoseKernel's host arithmetic (tracking.cpp:42-65, 304-318): makeJTJ + LLT solve, SE3 exp.
-// Eigen::LLT / Sophus::SE3f::exp are defined as: unblocked Cholesky with left-to-right inner sums; the
-// Sophus 1.0 closed form with epsilon 1e-5f and sinf / cosf from the C library.
-bool solve6(const float* vals /*b[6], upper triangle[21]*/, float x[6]) {
-  float Cm[6][6], L[6][6];
-  int k = 6;
-  for (int r = 0; r < 6; ++r)
-    for (int c = r; c < 6; ++c) { Cm[r][c] = vals[k]; Cm[c][r] = vals[k]; ++k; }
-  for (int j = 0; j < 6; ++j) {
-    float d = Cm[j][j];
-    if (j > 0) { float sn = 0; for (int q = 0; q < j; ++q) sn += L[j][q] * L[j][q]; d -= sn; }
-    if (!(d > 0.f)) { for (int i = 0; i < 6; ++i) x[i] = 0.f; return false; }
-    d = std::sqrt(d);
-    L[j][j] = d;
-    for (int i = j + 1; i < 6; ++i) {
-      float v = Cm[i][j];
-      if (j > 0) { float sp = 0; for (int q = 0; q < j; ++q) sp += L[i][q] * L[j][q]; v -= sp; }
-      L[i][j] = v / d;
-    }
-  }
-  float yv[6];
-  for (int i = 0; i < 6; ++i) { float v = vals[i]; for (int q = 0; q < i; ++q) v -= L[i][q] * yv[q]; yv[i] = v / L[i][i]; }
-  for (int i = 5; i >= 0; --i) { float v = yv[i]; for (int q = i + 1; q < 6; ++q) v -= L[q][i] * x[q]; x[i] = v / L[i][i]; }
-  return true;
-}
-M4 se3_exp(const float a[6]) {
-  const float eps = 1e-5f;
-  const float ox = a[3], oy = a[4], oz = a[5];
-  const float theta_sq = (ox * ox + oy * oy) + oz * oz, theta = std::sqrt(theta_sq), half_theta = 0.5f * theta;
-  float imag_factor, real_factor;
-  if (theta_sq < eps * eps) {
-    const float theta_po4 = theta_sq * theta_sq;
-    imag_factor = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
-    real_factor = 1.f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
-  } else {
-    imag_factor = sinf(half_theta) / theta;
-    real_factor = cosf(half_theta);
-  }
-  float qw = real_factor, qx = imag_factor * ox, qy = imag_factor * oy, qz = imag_factor * oz;
-  const float qn = std::sqrt(((qw * qw + qx * qx) + qy * qy) + qz * qz);
-  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
-  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
-  const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-  const float R[3][3] = {{1.f - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1.f - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1.f - (txx + tyy)}};
-  float V[3][3];
-  if (theta < eps) {
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = R[i][j];
-  } else {
-    const float Om[3][3] = {{0, -oz, oy}, {oz, 0, -ox}, {-oy, ox, 0}};
-    float Om2[3][3];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Om2[i][j] = (Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j]) + Om[i][2] * Om[2][j];
-    const float ca = (1.f - cosf(theta)) / theta_sq, cb = (theta - sinf(theta)) / (theta_sq * theta);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) V[i][j] = ((i == j ? 1.f : 0.f) + ca * Om[i][j]) + cb * Om2[i][j];
-  }
-  M4 T{};
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) T.m[i][j] = R[i][j];
-    T.m[i][3] = (V[i][0] * a[0] + V[i][1] * a[1]) + V[i][2] * a[2];
-  }
-  T.m[3][3] = 1.f;
-  return T;
-}
 M4 rigid_inverse(const M4& a) {   // raycast_pose_.inverse() of a rigid transform (DenseSLAMSystem.cpp:164)
   M4 r{};
   for (int i = 0; i < 3; ++i)
@@ -516,6 +453,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
 #endif
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_SYNC_SPIN")) p->sync_spin = std::atoi(ev) != 0;         // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
     int a = 0, b = 0, c = 0;
     if (std::sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3 && a >= b && b >= c && c >= 0 && a <= 1000) { p->prio_permille[0] = a; p->prio_permille[1] = b; p->prio_permille[2] = c; }
@@ -656,8 +594,8 @@ int se_hip_destroy(se_hip_pipeline* p) {
   if (p->track) hipFree(p->track);
   if (p->rgbw) hipFree(p->rgbw);
   if (p->reduce_partial) hipFree(p->reduce_partial);
-  if (p->reduce_out) hipFree(p->reduce_out);
-  if (p->reduce_host) hipHostFree(p->reduce_host);
+  if (p->icp) hipFree(p->icp);
+  if (p->icp_host) hipHostFree(p->icp_host);
   if (p->ctr_host) hipHostFree(p->ctr_host);
   if (p->gate_host) hipHostFree(p->gate_host);
   if (p->mesh_ctr) hipFree(p->mesh_ctr);
@@ -672,6 +610,11 @@ int se_hip_destroy(se_hip_pipeline* p) {
 
 int se_hip_sync(se_hip_pipeline* p) {
   if (int r = check(p)) return r;
+  // poll first: a frame of this path is tens of microseconds, a blocking wait wakes up later than that (closed loop: one sync per
+  // frame); after 2 ms of polling fall back to the blocking call.  SE_HIP_SYNC_SPIN=0 blocks at once.
+  if (p->sync_spin) {
+    spin_until([&] { return (!p->side || hipStreamQuery(p->side) != hipErrorNotReady) && hipStreamQuery(p->stream) != hipErrorNotReady; }, 2000);
+  }
   if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->gate_armed = false;   // every sweep enqueued so far is done
@@ -843,8 +786,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
-      // a wave covers 8 x (8 / SE_SCAN_SPLIT) pixels, SE_SCAN_SPLIT lanes per pixel (k_alloc_scan_sdf)
-      const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 8 / SE_SCAN_SPLIT - 1) / (8 / SE_SCAN_SPLIT));
+      const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);   // a wave = an 8x8 pixel tile
       const dim3 sgrid((tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
       if (m.dense) {
         if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, true>), sgrid, block, 0, s, ms, p->depth, a);
@@ -1230,9 +1172,9 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     HIP_TRY(hipMalloc((void**)&p->track, (size_t)W * H * sizeof(TrackData)));
     HIP_TRY(hipMemsetAsync(p->track, 0, (size_t)W * H * sizeof(TrackData), s));
     HIP_TRY(hipMalloc((void**)&p->reduce_partial, 8 * SE_TRACK_SEGMENTS * 32 * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&p->reduce_out, 8 * 32 * sizeof(float)));
-    HIP_TRY(hipHostMalloc((void**)&p->reduce_host, (8 * 32 + 16) * sizeof(float)));
-    std::memset(p->reduce_host, 0, (8 * 32 + 16) * sizeof(float));
+    HIP_TRY(hipMalloc((void**)&p->icp, sizeof(IcpState)));
+    HIP_TRY(hipHostMalloc((void**)&p->icp_host, sizeof(IcpHostRecord)));
+    std::memset(p->icp_host, 0, sizeof(IcpHostRecord));
   }
   // pyramid (DenseSLAMSystem.cpp:149-163): scaled_depth_[0] is the current depth image
   const float* d0 = p->depth;
@@ -1264,47 +1206,38 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     hipLaunchKernelGGL(k_depth2vertex, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_vertex[i], dsrc, w, h, ik);
     hipLaunchKernelGGL(k_vertex2normal, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_normal[i], p->pyr_vertex[i], w, h, k[1] < 0 ? 1 : 0);
   }
-  M4 pose = from_colmajor(pose_cm);
-  const M4 old_pose = pose;
+  // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, each
+  // one launch (trackKernel + reduceKernel + updatePoseKernel, k_icp_iter); the pose, the convergence flags and the sums
+  // travel from launch to launch in device memory, and the host reads one pinned record when k_icp_finish has run.
+  const M4 pose0 = from_colmajor(pose_cm);
   const M4 projectReference = mul(camera_matrix(k), rigid_inverse(from_colmajor(p->raycast_pose)));
   TrackArgs a{};
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) a.view[r * 4 + c] = projectReference.m[r][c];
   a.dist_threshold = 0.1f; a.normal_threshold = 0.8f;   // constant_parameters.h:19-20
   a.refW = W; a.refH = H;
-  int done = 0;
-  bool converged = false;
+  a.icp_threshold = icp_threshold;
+  Pose16 P0;
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) P0.m[r * 4 + c] = pose0.m[r][c];
+  hipLaunchKernelGGL(k_icp_begin, dim3(1), dim3(64), 0, s, p->icp, P0);
   for (int level = n_levels - 1; level >= 0; --level) {
-    const int w = W / (1 << level), h = H / (1 << level);
-    a.inW = w; a.inH = h;
-    for (int i = 0; i < pyramid[level]; ++i) {
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) a.T[r * 4 + c] = pose.m[r][c];
-      hipLaunchKernelGGL(k_track, dim3((w + 255) / 256, h), dim3(256), 0, s, p->track, p->pyr_vertex[level], p->pyr_normal[level], p->vertex, p->normal, a);
-      hipLaunchKernelGGL(k_track_reduce, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->reduce_partial, p->track, W, w, h);
-      volatile unsigned* seq_word = (volatile unsigned*)(p->reduce_host + 8 * 32);
-      const unsigned seq = ++p->reduce_seq;
-      hipLaunchKernelGGL(k_track_reduce_final, dim3(1), dim3(32), 0, s, p->reduce_out, p->reduce_partial, p->reduce_host, (unsigned*)seq_word, seq);
-      HIP_TRY(hipGetLastError());
-      // wait for the sums to land in pinned memory (bounded: 50 ms of wall clock, then a stream synchronisation)
-      if (!spin_until([&] { return *seq_word == seq; }, 50000)) {
-        HIP_TRY(hipStreamSynchronize(s));
-        if (*seq_word != seq) return fail(SE_HIP_E_DEVICE, "tracking reduction did not complete");
-      }
-      ++done;
-      float x[6];
-      solve6(p->reduce_host + 1, x);
-      pose = mul(se3_exp(x), pose);          // updatePoseKernel: pose = delta * pose
-      float xn = 0; for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
-      if (std::sqrt(xn) < icp_threshold) { converged = true; break; }
-    }
-    (void)converged;
+    a.inW = W / (1 << level); a.inH = H / (1 << level);
+    a.level = level;
+    for (int i = 0; i < pyramid[level]; ++i)
+      hipLaunchKernelGGL(k_icp_iter, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->icp, p->track, p->pyr_vertex[level], p->pyr_normal[level],
+                         p->vertex, p->normal, p->reduce_partial, a);
   }
-  p->track_iterations = done;
-  // checkPoseKernel (tracking.cpp:320-334)
-  const float* v = p->reduce_host;
-  bool tracked = true;
-  if ((std::sqrt(v[0] / v[28]) > 2e-2) || (v[28] / (W * H) < 0.15f)) { pose = old_pose; tracked = false; }
-  for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) pose_cm[c * 4 + r] = pose.m[r][c];
-  return tracked ? 1 : 0;
+  const unsigned seq = ++p->reduce_seq;
+  hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(64), 0, s, p->icp, p->icp_host, W, H, seq);
+  HIP_TRY(hipGetLastError());
+  // the one host wait of the frame: the record lands in pinned memory (bounded spin, then a stream synchronisation)
+  volatile unsigned* seq_word = &p->icp_host->seq;
+  if (!spin_until([&] { return *seq_word == seq; }, 200000)) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*seq_word != seq) return fail(SE_HIP_E_DEVICE, "tracking did not complete");
+  }
+  p->track_iterations = p->icp_host->iterations;
+  for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) pose_cm[c * 4 + r] = p->icp_host->pose[r * 4 + c];
+  return p->icp_host->tracked ? 1 : 0;
 }
 
 int se_hip_filter_depth(se_hip_pipeline* p, int32_t on) {
@@ -1327,7 +1260,7 @@ int se_hip_download_track(se_hip_pipeline* p, void* host_trackdata, float host_r
   if (int r = check(p)) return r;
   if (!p->track) return fail(SE_HIP_E_INVALID, "se_hip_track has not run");
   if (host_trackdata) HIP_TRY(hipMemcpy(host_trackdata, p->track, (size_t)p->cfg.width * p->cfg.height * sizeof(TrackData), hipMemcpyDeviceToHost));
-  if (host_reduce32) std::memcpy(host_reduce32, p->reduce_host, 32 * sizeof(float));
+  if (host_reduce32) std::memcpy(host_reduce32, p->icp_host->reduce0, 32 * sizeof(float));
   if (iterations) *iterations = p->track_iterations;
   return SE_HIP_OK;
 }

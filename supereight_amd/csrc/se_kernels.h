@@ -170,33 +170,31 @@ __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& 
     }
   }
 }
-// r03: (1) a step that stays in the block of the previous one is recognised by six float compares against that block's
-// bounds in voxel units (floor(s) in [8b, 8b+8) <=> s in [8b, 8b+8) for the integer bounds) -- the floor / range test /
-// float->int / shift sequence of the reference's loop body runs only when a step leaves the block (2-4 times per ray, and
-// for steps outside the volume); (2) SPLIT lanes share one pixel, lane j walking steps [j * chunk, (j + 1) * chunk) after
-// j * chunk bare additions voxelPos += step (the positions are defined by that accumulation, so they are replayed, not
-// computed from i * step): the launch is one round of resident waves whose duration is the length of one lane's dependent
-// chain, and that chain is what SPLIT shortens.  Block set, active flags and key list (as a set) are unchanged.
-#ifndef SE_SCAN_SPLIT
-#define SE_SCAN_SPLIT 1
+// r03, measured and dropped (profiles/r03_ab2_scan_pooled.log): (a) recognising a step that stays in the previous step's block by six
+// float compares against the block's bounds, the floor / range test / convert / shift sequence only on a crossing -- the 64 rays
+// of a wave cross block boundaries at different steps, so the wave executes both paths on nearly every step: 34.6 vs 32.2 us at
+// 512^3, 62.5 vs 57.4 us at 1024^3, 260 vs 247 us at 2048^3 beside the raycast; (b) two / four lanes per pixel, each walking
+// half / a quarter of the band after replaying the additions in front of it (shorter dependent chains, a single round of
+// waves): 34.0 / 38.3 us, 54.8 / 59.0 us, 282 / 289 us.  What stays is the straight-line loop body below.
+// (int)floorf(x), saturating, in one instruction
+__device__ __forceinline__ int se_cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#ifndef SE_SCAN_INT
+#define SE_SCAN_INT 1   // 1: block coordinates through v_cvt_flr_i32_f32 and one range test on the OR of the three integers (see below)
 #endif
 template <bool STATS, bool DENSE>
 __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
   __shared__ uint32_t s_blk_all[SE_SCAN_SLOTS * SE_WG_SCAN];
   uint32_t* s_blk = s_blk_all + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
-  constexpr int SPLIT = SE_SCAN_SPLIT;
-  constexpr int PXW = 8, PXH = 8 / SPLIT;          // pixels of one wave: 8 x 8, 8 x 4 or 8 x 2
-  int x, y, part;
+  int x, y;
   bool in_image;
   {
+    // a wave scans an 8x8 pixel tile: its rays cross the same 1-2 blocks per step (64 pixels of a row measured the same)
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
-    const int tiles_x = (a.W + PXW - 1) / PXW;
-    part = lane / (PXW * PXH);
-    const int pl = lane % (PXW * PXH);
-    x = (tile % tiles_x) * PXW + (pl % PXW);
-    y = a.row_begin + (tile / tiles_x) * PXH + (pl / PXW);
+    const int tiles_x = (a.W + 7) >> 3;
+    x = (tile % tiles_x) * 8 + (lane & 7);
+    y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
     in_image = x < a.W && y < a.row_end;
   }
   if (in_image) {
@@ -209,38 +207,51 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
       const f3 step = f3_div(f3_scale_r(direction, a.band), (float)a.num_steps);
       f3 voxelPos = origin;
       const float fsize = (float)m.size;
-      const int chunk = (a.num_steps + SPLIT - 1) / SPLIT;
-      const int i0 = part * chunk, i1 = min(a.num_steps, i0 + chunk);
-      for (int i = 0; i < i0; ++i) voxelPos = f3_add(voxelPos, step);      // replay of the accumulation up to this lane's first step
       uint32_t last = 0xFFFFFFFFu;   // last block recorded (probing it again changes nothing)
-      bool have = false;             // the previous step was inside the volume, in the block with these lower bounds (voxel units; upper = lower + 8)
-      float lox = 0.f, loy = 0.f, loz = 0.f;
       int nb = 0;
-      for (int i = i0; i < i1; ++i) {
+#if SE_SCAN_INT
+      // floor(s) as an integer in one instruction (v_cvt_flr_i32_f32 saturates, so a coordinate beyond +-2^31 stays outside);
+      // 0 <= floor(s.a) < size on all three axes <=> the OR of the three integers has no bit at or above log2(size) (size is a
+      // power of two; a negative integer has its sign bit set).  The reference's float tests are false for NaN, the conversion
+      // gives 0: a ray with a non-finite origin or step (depth = inf / NaN) is skipped up front, as the reference's tests would
+      // skip every one of its steps -- with finite origin and step no position is NaN.
+      const bool finite = fabsf(origin.x) < INFINITY && fabsf(origin.y) < INFINITY && fabsf(origin.z) < INFINITY &&
+                          fabsf(step.x) < INFINITY && fabsf(step.y) < INFINITY && fabsf(step.z) < INFINITY;
+      const uint32_t hi_mask = ~(uint32_t)(m.size - 1);
+      const int L = m.leaf_level;
+      for (int i = 0; finite && i < a.num_steps; ++i) {
         const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
-        const bool same = have && (s.x >= lox) && (s.x < lox + 8.f) && (s.y >= loy) && (s.y < loy + 8.f) && (s.z >= loz) && (s.z < loz + 8.f);
-        if (same) {
+        const int ix = se_cvt_flr(s.x), iy = se_cvt_flr(s.y), iz = se_cvt_flr(s.z);
+        if ((((uint32_t)ix | (uint32_t)iy | (uint32_t)iz) & hi_mask) == 0u) {
           ++probes;
-        } else {
-          const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
-          if ((vx < fsize) && (vy < fsize) && (vz < fsize) && (vx >= 0) && (vy >= 0) && (vz >= 0)) {
-            ++probes;
-            const int bx = (int)vx >> 3, by = (int)vy >> 3, bz = (int)vz >> 3;
-            const uint32_t lin = block_linear(m, bx, by, bz);
-            lox = (float)(bx << 3); loy = (float)(by << 3); loz = (float)(bz << 3);
-            have = true;
-            if (lin != last) {
-              last = lin;
-              if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
-              s_blk[nb * SE_WG_SCAN] = lin;
-              ++nb;
-            }
-          } else {
-            have = false;
+          const uint32_t lin = ((((uint32_t)iz >> 3) << L | ((uint32_t)iy >> 3)) << L) | ((uint32_t)ix >> 3);
+          if (lin != last) {
+            last = lin;
+            if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
+            s_blk[nb * SE_WG_SCAN] = lin;
+            ++nb;
           }
         }
         voxelPos = f3_add(voxelPos, step);
       }
+#else
+      for (int i = 0; i < a.num_steps; ++i) {
+        const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
+        const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
+        if ((vx < fsize) && (vy < fsize) && (vz < fsize) && (vx >= 0) && (vy >= 0) && (vz >= 0)) {
+          ++probes;
+          const uint32_t lin = block_linear(m, (int)vx >> 3, (int)vy >> 3, (int)vz >> 3);
+          if (lin != last) {
+            last = lin;
+            if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
+            s_blk[nb * SE_WG_SCAN] = lin;
+            ++nb;
+          }
+        }
+        voxelPos = f3_add(voxelPos, step);
+      }
+#endif
+      (void)fsize;
       if (nb) se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk);
     }
   }

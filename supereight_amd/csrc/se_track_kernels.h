@@ -1,11 +1,12 @@
 // the consumer side of the raycast -- image pyramid + ICP tracking
 // (se_denseslam/src/preprocessing.cpp, tracking.cpp) on the device, so that vertex_ / normal_ never
-// leave HBM.  Same arithmetic contract as the hot path (se_device.h).  The per-iteration 6x6 solve and
-// SE3 exponential stay on the host, as updatePoseKernel does in the reference (tracking.cpp:304-318).
+// leave HBM.  Same arithmetic contract as the hot path (se_device.h).  Since r03 the whole ICP loop is device-resident:
+// one launch per iteration (track + reduce + 6x6 solve + SE3 exponential + pose update + convergence test), one host read
+// per frame.
 #pragma once
 #include "se_device.h"
 
-#define SE_TRACK_SEGMENTS 16   // summation order of the reduction, see k_track_reduce
+#define SE_TRACK_SEGMENTS 32   // summation order of the reduction, see k_icp_iter (r03: 16 -> 32: one workgroup per compute unit)
 #define SE_TRACK_LANES 256
 
 struct TrackData { int result; float error; float J[6]; };   // se_denseslam/include/se/commons.h:249-253
@@ -90,21 +91,19 @@ __global__ void k_vertex2normal(float* __restrict__ out, const float* __restrict
 }
 
 struct TrackArgs {
-  float T[12];     // pose (Ttrack), rows 0..2
   float view[12];  // K * raycast_pose^-1, rows 0..2
   float dist_threshold, normal_threshold;
   int inW, inH, refW, refH;
+  int level;             // pyramid level of this iteration (IcpState::stop[level])
+  float icp_threshold;
 };
 
-// trackKernel (tracking.cpp:226-302): one thread per pixel of the pyramid level
-__global__ __launch_bounds__(256) void k_track(TrackData* __restrict__ output, const float* __restrict__ inVertex, const float* __restrict__ inNormal,
-                                               const float* __restrict__ refVertex, const float* __restrict__ refNormal, TrackArgs a) {
-  const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
-  if (px >= a.inW || py >= a.inH) return;
-  TrackData& row = output[px + py * a.refW];
+// trackKernel (tracking.cpp:226-302) for one pixel of the pyramid level.  A rejected pixel only gets `result`, as in the reference.
+__device__ __forceinline__ void se_track_pixel(TrackData& row, int px, int py, const float* __restrict__ inVertex, const float* __restrict__ inNormal,
+                                               const float* __restrict__ refVertex, const float* __restrict__ refNormal, const float* T, const TrackArgs& a) {
   const f3 inN = ld3(inNormal, px + py * a.inW);
   if (inN.x == -2.f) { row.result = -1; return; }
-  const f3 projectedVertex = m34_mul_h(a.T, ld3(inVertex, px + py * a.inW));
+  const f3 projectedVertex = m34_mul_h(T, ld3(inVertex, px + py * a.inW));
   const f3 projectedPos = m34_mul_h(a.view, projectedVertex);
   const float ppx = projectedPos.x / projectedPos.z + 0.5f, ppy = projectedPos.y / projectedPos.z + 0.5f;
   if (ppx < 0 || ppx > a.refW - 1 || ppy < 0 || ppy > a.refH - 1) { row.result = -2; return; }
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(256) void k_track(TrackData* __restrict__ output, c
   const f3 referenceNormal = ld3(refNormal, rx + ry * a.refW);
   if (referenceNormal.x == -2.f) { row.result = -3; return; }
   const f3 diff = f3_sub(ld3(refVertex, rx + ry * a.refW), projectedVertex);
-  const float R3[9] = {a.T[0], a.T[1], a.T[2], a.T[4], a.T[5], a.T[6], a.T[8], a.T[9], a.T[10]};
+  const float R3[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
   const f3 projectedNormal = m3_mul(R3, inN);
   if (sqrtf(f3_sqnorm(diff)) > a.dist_threshold) { row.result = -4; return; }
   if (f3_dot(projectedNormal, referenceNormal) < a.normal_threshold) { row.result = -5; return; }
@@ -142,28 +141,164 @@ __device__ __forceinline__ void se_accumulate_row(float* s, const TrackData& row
   s[28] += 1;
 }
 
-// reduceKernel (tracking.cpp:62-224).  The reference leaves the summation order to an OpenMP
-// reduction; here it is fixed: strip b = rows y = b (mod 8) as in the reference, split into
-// SE_TRACK_SEGMENTS contiguous segments (one workgroup each); lane t accumulates pixels t, t+256, ...
-// of its segment in order; the 256 partials are combined by a binary tree; k_track_reduce_final adds
-// the segments and then the strips in order.  grid = (SE_TRACK_SEGMENTS, 8).
-__global__ __launch_bounds__(SE_TRACK_LANES) void k_track_reduce(float* __restrict__ partial, const TrackData* __restrict__ J, int JW, int W, int H) {
+// ---- device-resident ICP (r03): the whole loop of DenseSLAMSystem::tracking (DenseSLAMSystem.cpp:165-186) runs without the host.
+// State that one iteration hands to the next lives in device memory; the host enqueues every iteration of every level up
+// front plus k_icp_finish, and reads ONE record per frame.  An iteration whose level has already met the convergence test
+// returns at once (the reference's `break`, tracking.cpp:180-183).
+struct IcpState {
+  float pose[16];      // current estimate, row-major 4x4 (Ttrack of the next iteration)
+  float old_pose[16];  // pose_ on entry (checkPoseKernel restores it)
+  float reduce0[32];   // row 0 of reduction_output_ of the last iteration that ran
+  int stop[8];         // per pyramid level: the update norm fell below icp_threshold -> the level's remaining iterations are skipped
+  int iterations;      // iterations that ran
+  unsigned ticket;     // workgroups of the running iteration that have delivered their partial sums
+  int tracked;
+};
+struct IcpHostRecord { float pose[16]; float reduce0[32]; int iterations; int tracked; unsigned seq; };
+
+// sin / cos of a float, DEFINED (oracle and device alike, see oracle/se_oracle.cpp so_sincos) as the correctly rounded result:
+// evaluated in double -- Cody-Waite reduction by pi/2 in two parts, the fdlibm kernel polynomials -- and rounded once.  Plain
+// IEEE double arithmetic in source order (no FMA contraction), so host and device agree bit for bit; it equals
+// (float)sin((double)x) of glibc for every one of 7.3e6 random arguments tried, and glibc's own sinf / cosf on 99.6 - 99.8 %
+// (they are 1 ulp off the correctly rounded value elsewhere).  Valid for |x| < 2^20 (ICP angle updates are << pi).
+__host__ __device__ inline void se_sincos_f32(float xf, float* s, float* c) {
+  const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00, PIO2_1T = 6.07710050650619224932e-11;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double x = (double)xf;
+  const double kd = rint(x * INV_PIO2);
+  const double r = (x - kd * PIO2_1) - kd * PIO2_1T;
+  const double z = r * r;
+  const double ks = r + (z * r) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+  const double kc = 1.0 - (0.5 * z - z * (z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))))));
+  const int n = (int)((long long)kd & 3);
+  const double sv = (n == 0) ? ks : (n == 1) ? kc : (n == 2) ? -ks : -kc;
+  const double cv = (n == 0) ? kc : (n == 1) ? -ks : (n == 2) ? -kc : ks;
+  *s = (float)sv; *c = (float)cv;
+}
+
+// updatePoseKernel's arithmetic (tracking.cpp:42-65, 304-318): makeJTJ + LLT solve.  Eigen::LLT is defined as the unblocked
+// Cholesky with left-to-right inner sums (oracle: solve6).
+__device__ inline bool se_solve6(const float* vals /*b[6], upper triangle[21]*/, float x[6]) {
+  float Cm[6][6], L[6][6];
+  int k = 6;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) { Cm[r][c] = vals[k]; Cm[c][r] = vals[k]; ++k; }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = Cm[j][j];
+    if (j > 0) { float sn = 0; for (int q = 0; q < j; ++q) sn += L[j][q] * L[j][q]; d -= sn; }
+    if (!(d > 0.f)) { for (int i = 0; i < 6; ++i) x[i] = 0.f; return false; }
+    d = sqrtf(d);
+    L[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float v = Cm[i][j];
+      if (j > 0) { float sp = 0; for (int q = 0; q < j; ++q) sp += L[i][q] * L[j][q]; v -= sp; }
+      L[i][j] = v / d;
+    }
+  }
+  float yv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { float v = vals[i]; for (int q = 0; q < i; ++q) v -= L[i][q] * yv[q]; yv[i] = v / L[i][i]; }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) { float v = yv[i]; for (int q = i + 1; q < 6; ++q) v -= L[q][i] * x[q]; x[i] = v / L[i][i]; }
+  return true;
+}
+// Sophus::SE3f::exp (tracking.cpp:310), Sophus 1.0 closed form with epsilon 1e-5f (oracle: se3_exp); T = row-major 4x4
+__device__ inline void se_se3_exp(const float a[6], float T[16]) {
+  const float eps = 1e-5f;
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = (ox * ox + oy * oy) + oz * oz, theta = sqrtf(theta_sq), half_theta = 0.5f * theta;
+  float imag_factor, real_factor;
+  if (theta_sq < eps * eps) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+    real_factor = 1.f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+  } else {
+    float sh, ch;
+    se_sincos_f32(half_theta, &sh, &ch);
+    imag_factor = sh / theta;
+    real_factor = ch;
+  }
+  float qw = real_factor, qx = imag_factor * ox, qy = imag_factor * oy, qz = imag_factor * oz;
+  const float qn = sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+  const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const float R[3][3] = {{1.f - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1.f - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1.f - (txx + tyy)}};
+  float V[3][3];
+  if (theta < eps) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = R[i][j];
+  } else {
+    const float Om[3][3] = {{0, -oz, oy}, {oz, 0, -ox}, {-oy, ox, 0}};
+    float Om2[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Om2[i][j] = (Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j]) + Om[i][2] * Om[2][j];
+    float st, ct;
+    se_sincos_f32(theta, &st, &ct);
+    const float ca = (1.f - ct) / theta_sq, cb = (theta - st) / (theta_sq * theta);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) V[i][j] = ((i == j ? 1.f : 0.f) + ca * Om[i][j]) + cb * Om2[i][j];
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i][j];
+    T[i * 4 + 3] = (V[i][0] * a[0] + V[i][1] * a[1]) + V[i][2] * a[2];
+  }
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+struct Pose16 { float m[16]; };   // row-major 4x4
+__global__ void k_icp_begin(IcpState* s, Pose16 pose) {
+  const int i = threadIdx.x;
+  if (i < 16) { s->pose[i] = pose.m[i]; s->old_pose[i] = pose.m[i]; }
+  if (i < 32) s->reduce0[i] = 0.f;
+  if (i < 8) s->stop[i] = 0;
+  if (i == 0) { s->iterations = 0; s->ticket = 0u; s->tracked = 0; }
+}
+
+// One ICP iteration = trackKernel + reduceKernel + updatePoseKernel (tracking.cpp:62-318) in ONE launch.
+// grid = (SE_TRACK_SEGMENTS, 8).  The reference leaves the summation order of the reduction to OpenMP; here (and in the oracle)
+// it is fixed: strip b = rows y = b (mod 8) as in the reference, split into SE_TRACK_SEGMENTS contiguous segments, one workgroup
+// each; lane t computes the TrackData of pixels t, t+256, ... of its segment and accumulates them in that order; the 256
+// partials are combined by a binary tree; the LAST workgroup to finish (ticket counter) adds the segments, then the strips, in
+// order, solves the 6x6 system, applies exp(x) to the pose and evaluates the convergence test, all in the oracle's order.
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(IcpState* __restrict__ s, TrackData* __restrict__ output, const float* __restrict__ inVertex,
+                                                              const float* __restrict__ inNormal, const float* __restrict__ refVertex,
+                                                              const float* __restrict__ refNormal, float* __restrict__ partial, TrackArgs a) {
   __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
+  __shared__ int s_last;
+  if (s->stop[a.level]) return;                 // the level has converged: `break` (uniform over the launch: set by a previous launch only)
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = s->pose[i];
+  const int W = a.inW, H = a.inH;
   const int rows = (H - b + 7) / 8;
   const long npx = (long)rows * W;
   const long seg_len = (npx + SE_TRACK_SEGMENTS - 1) / SE_TRACK_SEGMENTS;
   const long lo = g * seg_len, hi = min(npx, (g + 1) * seg_len);
-  float s[32];
+  float acc[32];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) s[i] = 0.f;
+  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
   for (long i = lo + t; i < hi; i += SE_TRACK_LANES) {
     const int y = b + 8 * (int)(i / W), x = (int)(i % W);
-    const TrackData row = J[x + y * JW];
-    se_accumulate_row(s, row);
+    TrackData row;
+    row.error = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) row.J[j] = 0.f;
+    se_track_pixel(row, x, y, inVertex, inNormal, refVertex, refNormal, T, a);
+    TrackData& dst = output[x + y * a.refW];
+    dst.result = row.result;
+    if (row.result == 1) { dst.error = row.error; for (int j = 0; j < 6; ++j) dst.J[j] = row.J[j]; }   // (a rejected pixel keeps its stale error / J, as in the reference)
+    se_accumulate_row(acc, row);
   }
 #pragma unroll
-  for (int i = 0; i < 32; ++i) lanes[t][i] = s[i];
+  for (int i = 0; i < 32; ++i) lanes[t][i] = acc[i];
   __syncthreads();
   for (int st = SE_TRACK_LANES / 2; st > 0; st >>= 1) {
     if (t < st)
@@ -172,29 +307,56 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_track_reduce(float* __restri
     __syncthreads();
   }
   if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = lanes[0][t];
-}
-// The sums also go straight to pinned host memory, followed by a sequence word: updatePoseKernel's 6x6 solve runs on the
-// host once per ICP iteration, and polling that word costs a few microseconds where a device-to-host copy plus a stream
-// synchronisation cost ~10 (19 iterations per frame).
-__global__ void k_track_reduce_final(float* __restrict__ out /*8*32*/, const float* __restrict__ partial, float* host_out, unsigned* host_seq, unsigned seq) {
-  const int i = threadIdx.x;
-  if (i < 32) {
+  // hand-over to the last workgroup: agent-scope release, ticket, agent-scope acquire (the XCDs' L2s are not coherent)
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_last = atomicAdd(&s->ticket, 1u) == gridDim.x * gridDim.y - 1u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (t < 32) {
     float row0 = 0.f;
-    float rows[8];
-    for (int b = 0; b < 8; ++b) {
+    for (int bb = 0; bb < 8; ++bb) {
       float total = 0.f;
-      for (int g = 0; g < SE_TRACK_SEGMENTS; ++g) total += partial[(b * SE_TRACK_SEGMENTS + g) * 32 + i];
-      rows[b] = total;
-      if (b == 0) row0 = total; else row0 += total;
+      for (int gg = 0; gg < SE_TRACK_SEGMENTS; ++gg) total += __builtin_nontemporal_load(&partial[(bb * SE_TRACK_SEGMENTS + gg) * 32 + t]);
+      if (bb == 0) row0 = total; else row0 += total;
     }
-    rows[0] = row0;
-    for (int b = 0; b < 8; ++b) { out[b * 32 + i] = rows[b]; if (host_out) host_out[b * 32 + i] = rows[b]; }
+    lanes[0][t] = row0;
+    s->reduce0[t] = row0;
   }
-  if (host_seq) {
-    __threadfence_system();
-    __syncthreads();
-    if (i == 0) { *(volatile unsigned*)host_seq = seq; }
+  __syncthreads();
+  if (t == 0) {
+    float x[6], D[16], P[16], N[16];
+    se_solve6(&lanes[0][1], x);
+    se_se3_exp(x, D);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = s->pose[i];
+    // updatePoseKernel: pose = delta * pose (4x4 product, inner sums left to right)
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        N[i * 4 + j] = ((D[i * 4 + 0] * P[0 * 4 + j] + D[i * 4 + 1] * P[1 * 4 + j]) + D[i * 4 + 2] * P[2 * 4 + j]) + D[i * 4 + 3] * P[3 * 4 + j];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s->pose[i] = N[i];
+    float xn = 0.f;
+    for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
+    if (sqrtf(xn) < a.icp_threshold) s->stop[a.level] = 1;
+    s->iterations = s->iterations + 1;
+    s->ticket = 0u;
   }
+}
+
+// checkPoseKernel (tracking.cpp:320-334) + the one record the host reads per frame (pinned memory, sequence word last)
+__global__ void k_icp_finish(IcpState* __restrict__ s, IcpHostRecord* __restrict__ host, int W, int H, unsigned seq) {
+  if (threadIdx.x != 0) return;
+  const float* v = s->reduce0;
+  const bool bad = ((double)sqrtf(v[0] / v[28]) > 2e-2) || (v[28] / (W * H) < 0.15f);
+  for (int i = 0; i < 16; ++i) host->pose[i] = bad ? s->old_pose[i] : s->pose[i];
+  for (int i = 0; i < 32; ++i) host->reduce0[i] = v[i];
+  host->iterations = s->iterations;
+  host->tracked = bad ? 0 : 1;
+  s->tracked = bad ? 0 : 1;
+  __threadfence_system();
+  *(volatile unsigned*)&host->seq = seq;
 }
 
 // renderTrackKernel (rendering.cpp:154-213)
