@@ -261,10 +261,11 @@ def oracle_bilateral_filter(depth):
     return out
 
 
-def oracle_tracking(depth, k, pose, raycast_pose, ref_vertex, ref_normal, icp_threshold=1e-5, pyramid=(10, 5, 4)):
-    """DenseSLAMSystem::tracking on the oracle.  Returns (tracked, new_pose 4x4, TrackData image, reduce row, iterations)."""
+def oracle_tracking(depth, k, pose, raycast_pose, ref_vertex, ref_normal, icp_threshold=1e-5, pyramid=(10, 5, 4), fma=False):
+    """DenseSLAMSystem::tracking on the oracle.  Returns (tracked, new_pose 4x4, TrackData image, reduce row, iterations).
+    fma=True: the noise-floor build (-ffp-contract=fast), see oracle/Makefile."""
     from supereight_amd.synthetic import to_colmajor
-    lib = load()
+    lib = load(fma=fma)
     H, W = depth.shape
     pose_cm = to_colmajor(pose).copy()
     track = np.zeros(W * H, TRACK_DTYPE)

@@ -93,7 +93,6 @@ struct se_hip_pipeline {
   bool own_side = false;       // false after se_hip_set_scan_stream handed one in
   hipEvent_t ev_sweep = nullptr, ev_scan = nullptr;
   bool overlap = false;
-  bool sync_spin = true;       // se_hip_sync polls before it blocks (SE_HIP_SYNC_SPIN=0: off)
   // host gate (see RayArgs::gate): replaces the event between the sweep and the next frame's scan for unsharded replicas
   bool host_gate = false;
   uint32_t* gate_host = nullptr;   // pinned word the raycast kernel writes its sequence number to
@@ -170,6 +169,7 @@ struct se_hip_pipeline {
   unsigned short* tile_cost = nullptr;   // raycast scheduling hint: per wave tile, cost in the previous launch (see RayArgs)
   int* prio_thr = nullptr;               // its three priority thresholds (device; written by the integration sweep)
   bool prio_hint = true;                 // SE_HIP_PRIO=0 switches the hint off
+  int prio_base = 0;                     // SE_HIP_PRIO_BASE: added to every raycast wave's priority
   int prio_permille[3] = {400, 150, 50}; // share of the tiles raised to priority >= 1 / >= 2 / 3 (SE_HIP_PRIO_SHARE="a,b,c", per mille)
   uint32_t* ray_order = nullptr;   // raycast schedule: the workgroups' tile pairs by descending previous cost (RayArgs::ray_order)
   int n_cus = 256;
@@ -303,6 +303,7 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.tile_cost = p->prio_hint ? p->tile_cost : nullptr;
   a.prio_thr = p->prio_thr;
   a.cost_shift = std::max(0, p->leaf_level - 6);
+  a.prio_base = p->prio_base;
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
@@ -453,7 +454,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
 #endif
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
-  if (const char* ev = std::getenv("SE_HIP_SYNC_SPIN")) p->sync_spin = std::atoi(ev) != 0;         // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_PRIO_BASE")) p->prio_base = std::max(0, std::min(3, std::atoi(ev)));   // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
     int a = 0, b = 0, c = 0;
     if (std::sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3 && a >= b && b >= c && c >= 0 && a <= 1000) { p->prio_permille[0] = a; p->prio_permille[1] = b; p->prio_permille[2] = c; }
@@ -610,11 +611,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
 
 int se_hip_sync(se_hip_pipeline* p) {
   if (int r = check(p)) return r;
-  // poll first: a frame of this path is tens of microseconds, a blocking wait wakes up later than that (closed loop: one sync per
-  // frame); after 2 ms of polling fall back to the blocking call.  SE_HIP_SYNC_SPIN=0 blocks at once.
-  if (p->sync_spin) {
-    spin_until([&] { return (!p->side || hipStreamQuery(p->side) != hipErrorNotReady) && hipStreamQuery(p->stream) != hipErrorNotReady; }, 2000);
-  }
+  // (polling hipStreamQuery before blocking was tried for the closed loop, one sync per frame: 10.3 k vs 10.8 k frames/s -- worse)
   if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   HIP_TRY(hipStreamSynchronize(p->stream));
   p->gate_armed = false;   // every sweep enqueued so far is done
@@ -1207,7 +1204,7 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     hipLaunchKernelGGL(k_vertex2normal, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_normal[i], p->pyr_vertex[i], w, h, k[1] < 0 ? 1 : 0);
   }
   // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, each
-  // one launch (trackKernel + reduceKernel + updatePoseKernel, k_icp_iter); the pose, the convergence flags and the sums
+  // two launches (k_icp_track: trackKernel + reduceKernel's partial sums; k_icp_update: final sums + updatePoseKernel); the pose, the convergence flags and the sums
   // travel from launch to launch in device memory, and the host reads one pinned record when k_icp_finish has run.
   const M4 pose0 = from_colmajor(pose_cm);
   const M4 projectReference = mul(camera_matrix(k), rigid_inverse(from_colmajor(p->raycast_pose)));
@@ -1222,9 +1219,11 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   for (int level = n_levels - 1; level >= 0; --level) {
     a.inW = W / (1 << level); a.inH = H / (1 << level);
     a.level = level;
-    for (int i = 0; i < pyramid[level]; ++i)
-      hipLaunchKernelGGL(k_icp_iter, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->icp, p->track, p->pyr_vertex[level], p->pyr_normal[level],
+    for (int i = 0; i < pyramid[level]; ++i) {
+      hipLaunchKernelGGL(k_icp_track, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->icp, p->track, p->pyr_vertex[level], p->pyr_normal[level],
                          p->vertex, p->normal, p->reduce_partial, a);
+      hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(256), 0, s, p->icp, p->reduce_partial, a);
+    }
   }
   const unsigned seq = ++p->reduce_seq;
   hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(64), 0, s, p->icp, p->icp_host, W, H, seq);

@@ -903,6 +903,7 @@ struct RayArgs {
   uint32_t* gate;
   uint32_t gate_seq;
   unsigned short* tile_cost;
+  int prio_base;       // added to every wave's priority (SE_HIP_PRIO_BASE)
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
                        // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
@@ -1543,9 +1544,11 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   if (a.tile_cost) {
     // (clamped like the histogram bins the thresholds come from; 256 = "no tile gets this priority")
     const int prev = min(__builtin_amdgcn_readfirstlane((int)a.tile_cost[tile_slot]), 255);
-    if (prev >= a.prio_thr[2]) __builtin_amdgcn_s_setprio(3);
-    else if (prev >= a.prio_thr[1]) __builtin_amdgcn_s_setprio(2);
-    else if (prev >= a.prio_thr[0]) __builtin_amdgcn_s_setprio(1);
+    int pr = prev >= a.prio_thr[2] ? 3 : (prev >= a.prio_thr[1] ? 2 : (prev >= a.prio_thr[0] ? 1 : 0));
+    pr = min(3, pr + a.prio_base);     // prio_base 1: every raycast wave outranks the allocation scan running beside it (tuning knob, default 0)
+    if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
   }
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
 #ifdef SE_DIAG

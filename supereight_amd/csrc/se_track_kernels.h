@@ -1,12 +1,12 @@
 // the consumer side of the raycast -- image pyramid + ICP tracking
 // (se_denseslam/src/preprocessing.cpp, tracking.cpp) on the device, so that vertex_ / normal_ never
 // leave HBM.  Same arithmetic contract as the hot path (se_device.h).  Since r03 the whole ICP loop is device-resident:
-// one launch per iteration (track + reduce + 6x6 solve + SE3 exponential + pose update + convergence test), one host read
-// per frame.
+// two launches per iteration (track + reduce; final sums + 6x6 solve + SE3 exponential + pose update + convergence test)
+// with the state in device memory, one host read per frame.
 #pragma once
 #include "se_device.h"
 
-#define SE_TRACK_SEGMENTS 32   // summation order of the reduction, see k_icp_iter (r03: 16 -> 32: one workgroup per compute unit)
+#define SE_TRACK_SEGMENTS 128  // summation order of the reduction, see k_icp_track (r03: 16 -> 128: ~1 pixel per lane at 640x480, the pixel phase is one round of loads)
 #define SE_TRACK_LANES 256
 
 struct TrackData { int result; float error; float J[6]; };   // se_denseslam/include/se/commons.h:249-253
@@ -151,7 +151,6 @@ struct IcpState {
   float reduce0[32];   // row 0 of reduction_output_ of the last iteration that ran
   int stop[8];         // per pyramid level: the update norm fell below icp_threshold -> the level's remaining iterations are skipped
   int iterations;      // iterations that ran
-  unsigned ticket;     // workgroups of the running iteration that have delivered their partial sums
   int tracked;
 };
 struct IcpHostRecord { float pose[16]; float reduce0[32]; int iterations; int tracked; unsigned seq; };
@@ -258,21 +257,26 @@ __global__ void k_icp_begin(IcpState* s, Pose16 pose) {
   if (i < 16) { s->pose[i] = pose.m[i]; s->old_pose[i] = pose.m[i]; }
   if (i < 32) s->reduce0[i] = 0.f;
   if (i < 8) s->stop[i] = 0;
-  if (i == 0) { s->iterations = 0; s->ticket = 0u; s->tracked = 0; }
+  if (i == 0) { s->iterations = 0; s->tracked = 0; }
 }
 
-// One ICP iteration = trackKernel + reduceKernel + updatePoseKernel (tracking.cpp:62-318) in ONE launch.
-// grid = (SE_TRACK_SEGMENTS, 8).  The reference leaves the summation order of the reduction to OpenMP; here (and in the oracle)
-// it is fixed: strip b = rows y = b (mod 8) as in the reference, split into SE_TRACK_SEGMENTS contiguous segments, one workgroup
-// each; lane t computes the TrackData of pixels t, t+256, ... of its segment and accumulates them in that order; the 256
-// partials are combined by a binary tree; the LAST workgroup to finish (ticket counter) adds the segments, then the strips, in
-// order, solves the 6x6 system, applies exp(x) to the pose and evaluates the convergence test, all in the oracle's order.
-__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(IcpState* __restrict__ s, TrackData* __restrict__ output, const float* __restrict__ inVertex,
-                                                              const float* __restrict__ inNormal, const float* __restrict__ refVertex,
-                                                              const float* __restrict__ refNormal, float* __restrict__ partial, TrackArgs a) {
+// One ICP iteration = two launches, no host in between.
+//  k_icp_track  = trackKernel + the first two stages of reduceKernel (tracking.cpp:62-302).  grid = (SE_TRACK_SEGMENTS, 8).  The
+//    reference leaves the summation order of the reduction to OpenMP; here (and in the oracle) it is fixed: strip b = rows
+//    y = b (mod 8) as in the reference, split into SE_TRACK_SEGMENTS contiguous segments, one workgroup each; lane t computes the
+//    TrackData of pixels t, t+256, ... of its segment and accumulates them in that order; the 256 partials are combined by a
+//    binary tree.
+//  k_icp_update = the rest of reduceKernel + updatePoseKernel (tracking.cpp:205-224, 304-318): per strip the segments are added in
+//    order (8 x 32 lanes in parallel), then the strips in order; one lane solves the 6x6 system, applies exp(x) to the pose and
+//    evaluates the convergence test, all in the oracle's order; pose, flags and sums stay in device memory for the next launch.
+// (A single launch per iteration with a last-workgroup ticket was built first and was slower: 25 us per iteration against 16 for
+//  r02's three launches + host round trip -- 256 workgroups each paid an agent-scope fence and an atomic on one word, and ~5 pixels
+//  per lane made the pixel phase five dependent rounds of gathers.)
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __restrict__ s, TrackData* __restrict__ output, const float* __restrict__ inVertex,
+                                                               const float* __restrict__ inNormal, const float* __restrict__ refVertex,
+                                                               const float* __restrict__ refNormal, float* __restrict__ partial, TrackArgs a) {
   __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
-  __shared__ int s_last;
-  if (s->stop[a.level]) return;                 // the level has converged: `break` (uniform over the launch: set by a previous launch only)
+  if (s->stop[a.level]) return;                 // the level has converged: the reference's `break` (set by an earlier launch only)
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
   float T[12];
 #pragma unroll
@@ -307,41 +311,41 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(IcpState* __restric
     __syncthreads();
   }
   if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = lanes[0][t];
-  // hand-over to the last workgroup: agent-scope release, ticket, agent-scope acquire (the XCDs' L2s are not coherent)
-  __threadfence();
+}
+
+__global__ __launch_bounds__(256) void k_icp_update(IcpState* __restrict__ s, const float* __restrict__ partial, TrackArgs a) {
+  __shared__ float strip[8][32];
+  if (s->stop[a.level]) return;
+  const int t = threadIdx.x, bb = t >> 5, i = t & 31;
+  {
+    float total = 0.f;
+    for (int gg = 0; gg < SE_TRACK_SEGMENTS; ++gg) total += partial[(bb * SE_TRACK_SEGMENTS + gg) * 32 + i];
+    strip[bb][i] = total;
+  }
   __syncthreads();
-  if (t == 0) s_last = atomicAdd(&s->ticket, 1u) == gridDim.x * gridDim.y - 1u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
   if (t < 32) {
-    float row0 = 0.f;
-    for (int bb = 0; bb < 8; ++bb) {
-      float total = 0.f;
-      for (int gg = 0; gg < SE_TRACK_SEGMENTS; ++gg) total += __builtin_nontemporal_load(&partial[(bb * SE_TRACK_SEGMENTS + gg) * 32 + t]);
-      if (bb == 0) row0 = total; else row0 += total;
-    }
-    lanes[0][t] = row0;
+    float row0 = strip[0][t];
+    for (int b2 = 1; b2 < 8; ++b2) row0 += strip[b2][t];
+    strip[0][t] = row0;
     s->reduce0[t] = row0;
   }
   __syncthreads();
   if (t == 0) {
     float x[6], D[16], P[16], N[16];
-    se_solve6(&lanes[0][1], x);
+    se_solve6(&strip[0][1], x);
     se_se3_exp(x, D);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) P[i] = s->pose[i];
+    for (int q = 0; q < 16; ++q) P[q] = s->pose[q];
     // updatePoseKernel: pose = delta * pose (4x4 product, inner sums left to right)
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j)
-        N[i * 4 + j] = ((D[i * 4 + 0] * P[0 * 4 + j] + D[i * 4 + 1] * P[1 * 4 + j]) + D[i * 4 + 2] * P[2 * 4 + j]) + D[i * 4 + 3] * P[3 * 4 + j];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c)
+        N[r * 4 + c] = ((D[r * 4 + 0] * P[0 * 4 + c] + D[r * 4 + 1] * P[1 * 4 + c]) + D[r * 4 + 2] * P[2 * 4 + c]) + D[r * 4 + 3] * P[3 * 4 + c];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s->pose[i] = N[i];
+    for (int q = 0; q < 16; ++q) s->pose[q] = N[q];
     float xn = 0.f;
     for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
     if (sqrtf(xn) < a.icp_threshold) s->stop[a.level] = 1;
     s->iterations = s->iterations + 1;
-    s->ticket = 0u;
   }
 }
 

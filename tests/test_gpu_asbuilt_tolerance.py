@@ -162,3 +162,58 @@ def test_asbuilt_distance_within_the_references_own_build_spread(name, field, ki
         fma.close(); off.close(); gpu.close()
     finally:
         lib.so_set_sophus_quat(0)
+
+
+def test_tracked_pose_stays_near_the_as_built_reference():
+    """the closed SLAM loop (tracking -> integration -> raycasting, GT poses for frames 0..3 only) on the HIP
+    path against the same loop on the as-built oracle variant (FMA contraction + Sophus quaternion round trip): after 30
+    tracked frames at 640x480 -> 512^3 the two pose estimates must agree to 0.5 mm in translation and 2e-4 in every rotation-matrix
+    entry.  Measured between the two CPU builds of the restatement (to which the HIP path is bit-identical on the
+    contraction-off side): 0.05 mm / 1.6e-5 at frame 33, never above 0.07 mm / 2.2e-5 on the way; both drift ~4 mm from the
+    ground truth (the reference's ICP under-tracks this noise-free box room)."""
+    from oracle.binding import oracle_tracking
+    lib = load(fma=True)
+    assert lib.so_fp_contract() == 1
+    lib.so_set_sophus_quat(1)
+    try:
+        frames, mu = 34, 0.1
+        s = SyntheticStream(W, H, DIM)
+        ref = OraclePipeline(SDF, N, DIM, W, H, fma=True)
+        gpu = DenseSLAMPipeline((W, H), N, DIM, field_type=SDF)
+        pose_r = s.pose(0).copy()
+        gpu.setPose(s.pose(0))
+        v_r = n_r = rp_r = None
+        worst_t = worst_r = 0.0
+        for f in range(frames):
+            d = s.depth(f)
+            gpu.set_depth(d)
+            if f >= 4:
+                ok_r, pose_r, _, _, _ = oracle_tracking(d, s.k, pose_r, rp_r, v_r, n_r, 1e-5, (10, 5, 4), fma=True)
+                ok_g = gpu.tracking(s.k, 1e-5, 1, f, (10, 5, 4))
+                assert ok_r and ok_g
+            else:
+                pose_r = s.pose(f).copy()
+                gpu.setPose(pose_r)
+            ref.integrate(d, pose_r, s.k, mu, f)
+            gpu.integration(s.k, 1, mu, f)
+            ran, vv, nn = ref.raycast(pose_r, s.k, mu, f)
+            gpu.raycasting(s.k, mu, f)
+            if ran:
+                v_r, n_r, rp_r = vv, nn, pose_r.copy()
+            pg = gpu.getPose()
+            worst_t = max(worst_t, float(np.abs(pg[:3, 3] - pose_r[:3, 3]).max()))
+            worst_r = max(worst_r, float(np.abs(pg[:3, :3] - pose_r[:3, :3]).max()))
+        pg = gpu.getPose()
+        dt, dr = float(np.abs(pg[:3, 3] - pose_r[:3, 3]).max()), float(np.abs(pg[:3, :3] - pose_r[:3, :3]).max())
+        gt = float(np.abs(pg[:3, 3] - s.pose(frames - 1)[:3, 3]).max())
+        report = {"config": f"{W}x{H} -> {N}^3 SDF, {frames - 4} tracked frames, HIP vs oracle(-ffp-contract=fast, Sophus quaternion)",
+                  "final_translation_diff_m": dt, "final_rotation_entry_diff": dr, "worst_translation_diff_m": worst_t, "worst_rotation_entry_diff": worst_r,
+                  "hip_vs_ground_truth_m": gt}
+        print(json.dumps(report))
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/asbuilt_tracking.json", "w") as fh:
+            json.dump(report, fh, indent=1)
+        assert worst_t < 5e-4 and worst_r < 2e-4, report
+        ref.close(); gpu.close()
+    finally:
+        lib.so_set_sophus_quat(0)
