@@ -271,8 +271,12 @@ def oracle_tracking(depth, k, pose, raycast_pose, ref_vertex, ref_normal, icp_th
     track = np.zeros(W * H, TRACK_DTYPE)
     red = np.zeros(32, np.float32)
     it = C.c_int()
+    # the ICP is thousands of small parallel regions: on a 256-thread box the OpenMP barriers cost more than the work
+    nthr = lib.so_num_threads()
+    lib.so_set_num_threads(min(nthr, 16))
     ok = lib.so_tracking(np.ascontiguousarray(depth, np.float32).reshape(-1), W, H, np.asarray(k, np.float32),
                          np.asarray(pyramid, np.int32), len(pyramid), icp_threshold,
                          np.ascontiguousarray(ref_vertex, np.float32).reshape(-1), np.ascontiguousarray(ref_normal, np.float32).reshape(-1),
                          to_colmajor(raycast_pose), pose_cm, track.ctypes.data, red, C.byref(it))
+    lib.so_set_num_threads(nthr)
     return bool(ok), pose_cm.reshape(4, 4).T.copy(), track.reshape(H, W), red, it.value

@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out_dir, tag = sys.argv[1], sys.argv[2]
-OURS = ("k_alloc", "k_integrate", "k_raycast", "k_fill", "k_occ_commit", "k_zero_chain", "k_mm2meters")
+OURS = ("k_alloc", "k_integrate", "k_raycast", "k_fill", "k_occ_commit", "k_zero_chain", "k_mm2meters", "k_icp", "k_half_sample", "k_depth2vertex", "k_vertex2normal", "k_bilateral")
 
 
 def short(name):
