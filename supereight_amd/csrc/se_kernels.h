@@ -902,6 +902,9 @@ struct RayArgs {
   // without an event-record packet between sweep(f) and raycast(f) on this queue.
   uint32_t* gate;
   uint32_t gate_seq;
+  int gate_pos;        // < 0: the gate is written when the launch starts (default).  >= 0: by the workgroup at this position of the
+                       // cost-sorted deal, when it FINISHES -- the next frame's scan is then released into the second half of the launch,
+                       // where the cheap tiles are done and SIMDs idle, instead of beside its issue-bound first half (SE_HIP_GATE_LATE)
   unsigned short* tile_cost;
   int prio_base;       // added to every wave's priority (SE_HIP_PRIO_BASE)
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
@@ -1508,7 +1511,7 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   uint32_t* s_occ = smem;
   uint32_t* s_par = smem + a.cache_words;
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
-  if (a.gate && blockIdx.x == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
+  if (a.gate && a.gate_pos < 0 && blockIdx.x == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef SE_DIAG
   const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
@@ -1528,11 +1531,13 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   const int tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
   const int n_tiles = tiles_x * tiles_y, n_pairs = (n_tiles + 1) >> 1;
   int tile;
+  bool gate_wg = false;
   {
     const int rnd = blockIdx.x / a.n_cus, cu = blockIdx.x - rnd * a.n_cus;
     const int pos = rnd * a.n_cus + ((rnd & 1) ? a.n_cus - 1 - cu : cu);
     const int pair = pos < n_pairs ? (int)a.ray_order[pos] : n_pairs;   // (positions of the last, partial round beyond the list: no pair)
     tile = 2 * pair + (threadIdx.x >> 6);
+    gate_wg = a.gate && a.gate_pos >= 0 && pos == min(a.gate_pos, n_pairs - 1);
   }
   int tx = tile % tiles_x, ty = tile / tiles_x;
   if (tile >= n_tiles) { tx = tiles_x; ty = 1 << 20; tile = 0; }   // no tile: fails the tests below
@@ -1605,6 +1610,10 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
       v[0] = 0.f; v[1] = 0.f; v[2] = 0.f;
       n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;
     }
+  }
+  if (gate_wg) {   // late host gate: both waves of this workgroup are done with their rays
+    __syncthreads();
+    if (threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   }
   if (a.tile_cost) {
     // wave maximum through the (now idle) first stack slot of this wave's lane 0; LDS operations of one wave are ordered

@@ -148,6 +148,7 @@ __device__ __forceinline__ void se_accumulate_row(float* s, const TrackData& row
 struct IcpState {
   float pose[16];      // current estimate, row-major 4x4 (Ttrack of the next iteration)
   float old_pose[16];  // pose_ on entry (checkPoseKernel restores it)
+  float last_pose[16]; // the pose the last iteration that ran tracked with (k_icp_rows rebuilds tracking_result_ from it)
   float reduce0[32];   // row 0 of reduction_output_ of the last iteration that ran
   int stop[8];         // per pyramid level: the update norm fell below icp_threshold -> the level's remaining iterations are skipped
   int iterations;      // iterations that ran
@@ -254,7 +255,7 @@ __device__ inline void se_se3_exp(const float a[6], float T[16]) {
 struct Pose16 { float m[16]; };   // row-major 4x4
 __global__ void k_icp_begin(IcpState* s, Pose16 pose) {
   const int i = threadIdx.x;
-  if (i < 16) { s->pose[i] = pose.m[i]; s->old_pose[i] = pose.m[i]; }
+  if (i < 16) { s->pose[i] = pose.m[i]; s->old_pose[i] = pose.m[i]; s->last_pose[i] = pose.m[i]; }
   if (i < 32) s->reduce0[i] = 0.f;
   if (i < 8) s->stop[i] = 0;
   if (i == 0) { s->iterations = 0; s->tracked = 0; }
@@ -272,7 +273,7 @@ __global__ void k_icp_begin(IcpState* s, Pose16 pose) {
 // (A single launch per iteration with a last-workgroup ticket was built first and was slower: 25 us per iteration against 16 for
 //  r02's three launches + host round trip -- 256 workgroups each paid an agent-scope fence and an atomic on one word, and ~5 pixels
 //  per lane made the pixel phase five dependent rounds of gathers.)
-__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __restrict__ s, TrackData* __restrict__ output, const float* __restrict__ inVertex,
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __restrict__ s, const float* __restrict__ inVertex,
                                                                const float* __restrict__ inNormal, const float* __restrict__ refVertex,
                                                                const float* __restrict__ refNormal, float* __restrict__ partial, TrackArgs a) {
   __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
@@ -296,10 +297,7 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __
 #pragma unroll
     for (int j = 0; j < 6; ++j) row.J[j] = 0.f;
     se_track_pixel(row, x, y, inVertex, inNormal, refVertex, refNormal, T, a);
-    TrackData& dst = output[x + y * a.refW];
-    dst.result = row.result;
-    if (row.result == 1) { dst.error = row.error; for (int j = 0; j < 6; ++j) dst.J[j] = row.J[j]; }   // (a rejected pixel keeps its stale error / J, as in the reference)
-    se_accumulate_row(acc, row);
+    se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_rows)
   }
 #pragma unroll
   for (int i = 0; i < 32; ++i) lanes[t][i] = acc[i];
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(256) void k_icp_update(IcpState* __restrict__ s, co
     se_solve6(&strip[0][1], x);
     se_se3_exp(x, D);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) P[q] = s->pose[q];
+    for (int q = 0; q < 16; ++q) { P[q] = s->pose[q]; s->last_pose[q] = P[q]; }
     // updatePoseKernel: pose = delta * pose (4x4 product, inner sums left to right)
     for (int r = 0; r < 4; ++r)
       for (int c = 0; c < 4; ++c)
@@ -347,6 +345,25 @@ __global__ __launch_bounds__(256) void k_icp_update(IcpState* __restrict__ s, co
     if (sqrtf(xn) < a.icp_threshold) s->stop[a.level] = 1;
     s->iterations = s->iterations + 1;
   }
+}
+
+// tracking_result_ (what renderTrackKernel shows and se_hip_download_track returns) as the reference leaves it after the frame's last
+// ICP iteration: one launch per tracked frame over the finest level that ran, with the pose that iteration tracked with -- instead
+// of 32 bytes per pixel stored by every one of the 19 iterations (10 MB each on the 640x480 level).  `result` of every pixel and
+// error / J of the accepted ones are the reference's; the reference's rejected pixels keep whatever an earlier iteration or
+// frame left in error / J, which nothing reads.
+__global__ __launch_bounds__(256) void k_icp_rows(const IcpState* __restrict__ s, TrackData* __restrict__ output, const float* __restrict__ inVertex,
+                                                  const float* __restrict__ inNormal, const float* __restrict__ refVertex, const float* __restrict__ refNormal, TrackArgs a) {
+  const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+  if (px >= a.inW || py >= a.inH) return;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = s->last_pose[i];
+  TrackData row;
+  se_track_pixel(row, px, py, inVertex, inNormal, refVertex, refNormal, T, a);
+  TrackData& dst = output[px + py * a.refW];
+  dst.result = row.result;
+  if (row.result == 1) { dst.error = row.error; for (int j = 0; j < 6; ++j) dst.J[j] = row.J[j]; }
 }
 
 // checkPoseKernel (tracking.cpp:320-334) + the one record the host reads per frame (pinned memory, sequence word last)
