@@ -89,6 +89,11 @@ class DenseSLAMSystem {
     // bilateralFilterKernel feeds only the tracking pyramid (scaled_depth_[0]); it runs inside se_hip_track
     return ok(se_hip_filter_depth(h_, filterInput ? 1 : 0)) && ok(se_hip_upload_depth_mm(h_, inputDepth, inputSize.x(), inputSize.y()));
   }
+  /* DenseSLAMSystem.h:154-157: declared with "TODO Implement this." in the reference and never defined; the RGB image has no
+   * consumer in the pipeline (se-denseslam is depth-only), so the overload forwards to the depth-only form. */
+  bool preprocessing(const unsigned short* inputDepth, const unsigned char* /*inputRGB*/, const Eigen::Vector2i& inputSize, const bool filterInput) {
+    return preprocessing(inputDepth, inputSize, filterInput);
+  }
   /* the reference's float_depth_ handed over directly (metres) */
   bool preprocessing(const float* depthMetres) { return ok(se_hip_upload_depth(h_, depthMetres)); }
 

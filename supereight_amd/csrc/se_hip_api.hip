@@ -169,8 +169,6 @@ struct se_hip_pipeline {
   unsigned short* tile_cost = nullptr;   // raycast scheduling hint: per wave tile, cost in the previous launch (see RayArgs)
   int* prio_thr = nullptr;               // its three priority thresholds (device; written by the integration sweep)
   bool prio_hint = true;                 // SE_HIP_PRIO=0 switches the hint off
-  int prio_base = 0;                     // SE_HIP_PRIO_BASE: added to every raycast wave's priority
-  int gate_late_permille = -1;           // SE_HIP_GATE_LATE: see RayArgs::gate_pos (-1: gate at the start of the raycast launch)
   int prio_permille[3] = {400, 150, 50}; // share of the tiles raised to priority >= 1 / >= 2 / 3 (SE_HIP_PRIO_SHARE="a,b,c", per mille)
   uint32_t* ray_order = nullptr;   // raycast schedule: the workgroups' tile pairs by descending previous cost (RayArgs::ray_order)
   int n_cus = 256;
@@ -304,7 +302,6 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.tile_cost = p->prio_hint ? p->tile_cost : nullptr;
   a.prio_thr = p->prio_thr;
   a.cost_shift = std::max(0, p->leaf_level - 6);
-  a.prio_base = p->prio_base;
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
@@ -455,8 +452,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
 #endif
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
-  if (const char* ev = std::getenv("SE_HIP_PRIO_BASE")) p->prio_base = std::max(0, std::min(3, std::atoi(ev)));   // tuning knob
-  if (const char* ev = std::getenv("SE_HIP_GATE_LATE")) p->gate_late_permille = std::max(-1, std::min(1000, std::atoi(ev)));   // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
     int a = 0, b = 0, c = 0;
     if (std::sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3 && a >= b && b >= c && c >= 0 && a <= 1000) { p->prio_permille[0] = a; p->prio_permille[1] = b; p->prio_permille[2] = c; }
@@ -1064,15 +1059,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   const DevMap& m = p->map;
   RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
-  L.a.gate_pos = -1;
-  if (p->host_gate) {
-    L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true;
-    if (p->gate_late_permille >= 0) {   // position in the cost-sorted deal (0 = costliest pair, 1000 = cheapest) whose workgroup writes the gate when it finishes
-      const int tiles_x = (L.a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (L.a.row_end - L.a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
-      const int n_pairs = (tiles_x * tiles_y + 1) / 2;
-      L.a.gate_pos = (int)((long long)(n_pairs - 1) * p->gate_late_permille / 1000);
-    }
-  }
+  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
   const RayArgs& a = L.a;
   const size_t smem = L.smem;
   const dim3 grid = L.grid, block(SE_WG_RAY);

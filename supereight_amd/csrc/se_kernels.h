@@ -902,11 +902,7 @@ struct RayArgs {
   // without an event-record packet between sweep(f) and raycast(f) on this queue.
   uint32_t* gate;
   uint32_t gate_seq;
-  int gate_pos;        // < 0: the gate is written when the launch starts (default).  >= 0: by the workgroup at this position of the
-                       // cost-sorted deal, when it FINISHES -- the next frame's scan is then released into the second half of the launch,
-                       // where the cheap tiles are done and SIMDs idle, instead of beside its issue-bound first half (SE_HIP_GATE_LATE)
   unsigned short* tile_cost;
-  int prio_base;       // added to every wave's priority (SE_HIP_PRIO_BASE)
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
                        // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
@@ -1504,14 +1500,19 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
+#ifdef SE_RAY_WAVES_PER_EU   // experiment: force the register budget of N waves per SIMD (8 -> 64 VGPRs)
+#define SE_RAY_OCC __attribute__((amdgpu_waves_per_eu(SE_RAY_WAVES_PER_EU, SE_RAY_WAVES_PER_EU)))
+#else
+#define SE_RAY_OCC
+#endif
 template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW>
-__global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
+__global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
   // LDS: [occupancy words of levels 1..cache_levels][ray stack: parent codes][ray stack: t_max]
   extern __shared__ uint32_t smem[];
   uint32_t* s_occ = smem;
   uint32_t* s_par = smem + a.cache_words;
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
-  if (a.gate && a.gate_pos < 0 && blockIdx.x == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
+  if (a.gate && blockIdx.x == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef SE_DIAG
   const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
@@ -1531,13 +1532,11 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   const int tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
   const int n_tiles = tiles_x * tiles_y, n_pairs = (n_tiles + 1) >> 1;
   int tile;
-  bool gate_wg = false;
   {
     const int rnd = blockIdx.x / a.n_cus, cu = blockIdx.x - rnd * a.n_cus;
     const int pos = rnd * a.n_cus + ((rnd & 1) ? a.n_cus - 1 - cu : cu);
     const int pair = pos < n_pairs ? (int)a.ray_order[pos] : n_pairs;   // (positions of the last, partial round beyond the list: no pair)
     tile = 2 * pair + (threadIdx.x >> 6);
-    gate_wg = a.gate && a.gate_pos >= 0 && pos == min(a.gate_pos, n_pairs - 1);
   }
   int tx = tile % tiles_x, ty = tile / tiles_x;
   if (tile >= n_tiles) { tx = tiles_x; ty = 1 << 20; tile = 0; }   // no tile: fails the tests below
@@ -1549,11 +1548,9 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
   if (a.tile_cost) {
     // (clamped like the histogram bins the thresholds come from; 256 = "no tile gets this priority")
     const int prev = min(__builtin_amdgcn_readfirstlane((int)a.tile_cost[tile_slot]), 255);
-    int pr = prev >= a.prio_thr[2] ? 3 : (prev >= a.prio_thr[1] ? 2 : (prev >= a.prio_thr[0] ? 1 : 0));
-    pr = min(3, pr + a.prio_base);     // prio_base 1: every raycast wave outranks the allocation scan running beside it (tuning knob, default 0)
-    if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    if (prev >= a.prio_thr[2]) __builtin_amdgcn_s_setprio(3);
+    else if (prev >= a.prio_thr[1]) __builtin_amdgcn_s_setprio(2);
+    else if (prev >= a.prio_thr[0]) __builtin_amdgcn_s_setprio(1);
   }
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
 #ifdef SE_DIAG
@@ -1610,10 +1607,6 @@ __global__ __launch_bounds__(SE_WG_RAY) void k_raycast(DevMap m, RayArgs a, floa
       v[0] = 0.f; v[1] = 0.f; v[2] = 0.f;
       n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;
     }
-  }
-  if (gate_wg) {   // late host gate: both waves of this workgroup are done with their rays
-    __syncthreads();
-    if (threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   }
   if (a.tile_cost) {
     // wave maximum through the (now idle) first stack slot of this wave's lane 0; LDS operations of one wave are ordered

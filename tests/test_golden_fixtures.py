@@ -6,25 +6,30 @@ import pytest
 
 from tests.golden_util import check_against_golden, load
 
-CASES = [("sdf_80x60_128.npz", 0), ("ofusion_80x60_128.npz", 1)]
+CASES = [("sdf_80x60_128.npz", 0), ("ofusion_80x60_128.npz", 1), ("stress_sdf_80x60_128.npz", 0), ("stress_ofusion_80x60_128.npz", 1)]
+IDS = ["sdf", "ofusion", "stress-sdf", "stress-ofusion"]
 
 
-@pytest.mark.parametrize("name,field", CASES, ids=["sdf", "ofusion"])
+@pytest.mark.parametrize("name,field", CASES, ids=IDS)
 def test_oracle_reproduces_golden(name, field):
     from oracle.binding import OraclePipeline
     g = load(name)
     W, H, N, F = (int(v) for v in g["dims"])
     o = OraclePipeline(field, N, float(g["dim"]), W, H)
+    o.count_stats(True)
     for f in range(F):
         o.integrate(g["depth"][f], g["pose"][f], g["k"], float(g["mu"]), f)
         ran, v, n = o.raycast(g["pose"][f], g["k"], float(g["mu"]), f)
     c, x, y, a = o.blocks()
     code, side, nx, ny = o.nodes()
     check_against_golden(g, c, x, y, a, code, nx, ny, v, n)
+    if name.startswith("stress"):     # the fixture is in the regime it claims: rays leave the volume, none hits a read the reference leaves undefined
+        st = o.stats()
+        assert st["oob"] == int(g["oob"]) > 0 and st["oob_ub"] == 0 and st["truncated"] == 0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,field", CASES, ids=["sdf", "ofusion"])
+@pytest.mark.parametrize("name,field", CASES, ids=IDS)
 @pytest.mark.parametrize("max_blocks", [0, 4096], ids=["dense", "pooled"])
 def test_hip_reproduces_golden(name, field, max_blocks):
     from supereight_amd.pipeline import DenseSLAMPipeline
