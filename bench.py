@@ -344,7 +344,7 @@ def pmc_traffic(kernel: str, args):
             continue
         w = d.get("workload", {})
         if (w.get("width"), w.get("height"), w.get("res"), w.get("field")) == (args.width, args.height, args.res, args.field) and \
-                abs(w.get("mu", args.mu) - args.mu) < 1e-9:
+                abs(w.get("mu", args.mu) - args.mu) < 1e-9 and w.get("stream", "room") == args.stream and not args.raw:
             if kernel in d.get("kernels", {}):
                 best = (d["kernels"][kernel]["traffic_bytes"], os.path.basename(path))
     return best

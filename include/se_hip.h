@@ -83,11 +83,11 @@ int se_hip_clear_overflow(se_hip_pipeline* p);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the handle's own. */
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
 /* The stream the allocation scan (se_hip_alloc_scan) is launched on when it overlaps the previous
- * frame's raycast (dense replicas).  The multi-GPU driver passes the stream its
+ * frame's raycast.  The multi-GPU driver passes the stream its
  * all-gather of the key lists is ordered on, so that scan + exchange of frame f+1 hide behind the
  * raycast of frame f.  NULL = a stream owned by the handle (the default). */
 int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
-/* 1 if the key list of se_hip_alloc_scan is produced on the scan stream (dense replicas, overlap on), 0 if on the main
+/* 1 if the key list of se_hip_alloc_scan is produced on the scan stream (overlap on: the default), 0 if on the main
  * stream like every other stage -- in which case work ordered with the scan (an all-gather of its list) belongs on the main
  * stream.  With overlap on, a handle that is row-sharded, writes its list into a caller buffer (se_hip_set_new_keys_buffer)
  * or has an exchange set (se_hip_set_exchange) ALWAYS scans on the scan stream; only a plain single handle whose main

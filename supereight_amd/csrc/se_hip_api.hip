@@ -88,7 +88,7 @@ struct se_hip_pipeline {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // side stream: the allocation scan (and the depth upload feeding it) of frame f+1 runs here,
-  // concurrently with the raycast of frame f on `stream` (dense, unsharded replicas only)
+  // concurrently with the raycast of frame f on `stream`
   hipStream_t side = nullptr;
   bool own_side = false;       // false after se_hip_set_scan_stream handed one in
   hipEvent_t ev_sweep = nullptr, ev_scan = nullptr;
