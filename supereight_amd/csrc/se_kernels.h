@@ -560,6 +560,60 @@ __device__ __forceinline__ int se_bspline_index(float t) {
   if (t > 3) return 1001;
   return 1000;
 }
+// ---- r03: two voxel slices per instruction.  The sweep is out of VALU issue slots (0.9 of them at 1024^3 / 2048^3) and a
+// third of its instructions are IEEE divisions.  gfx950 executes v_pk_{mul,add,fma}_f32 on two independent floats at the rate of
+// one, so the 8 z-slices of a lane are processed as 4 pairs: every multiplication / addition of the functor is one packed
+// instruction per pair, and the division is the compiler's own correctly rounded sequence (v_div_scale x2, v_rcp, fma, fma, mul,
+// fma, fma, fma, v_div_fmas, v_div_fixup -- AMDGPU's f32 fdiv lowering with denormals on) written out with its six fma / mul steps
+// packed: 16 instructions for two quotients instead of 22.  Same operations on the same operands in the same order per element:
+// the results are the scalar code's bit for bit (no contraction: the fma calls are the division's own).
+// Measured (profiles/r03_ab9_packed_sweep.log): bit-exact on every stream -- the hand-written division IS the compiler's -- and
+// 7 % fewer instructions, but no faster: sweep 26.6 vs 27.7 us at 512^3, 127.9 vs 123.5 at 1024^3, 862 vs 849 at 2048^3, where the
+// kernel runs within 15 % of its own copy-only speed (5.1 TB/s of scattered 2 KB rows).  Off by default, kept as the experiment.
+#ifndef SE_SWEEP_PACKED
+#define SE_SWEEP_PACKED 0
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f v2_splat(float s) { return (v2f){s, s}; }
+__device__ __forceinline__ v2f se_div2(v2f a, v2f b) {
+  bool f0, f1, d0, d1;
+  v2f ds, ns, r;
+  ds.x = __builtin_amdgcn_div_scalef(a.x, b.x, false, &d0);
+  ds.y = __builtin_amdgcn_div_scalef(a.y, b.y, false, &d1);
+  ns.x = __builtin_amdgcn_div_scalef(a.x, b.x, true, &f0);
+  ns.y = __builtin_amdgcn_div_scalef(a.y, b.y, true, &f1);
+  r.x = __builtin_amdgcn_rcpf(ds.x);
+  r.y = __builtin_amdgcn_rcpf(ds.y);
+  const v2f nds = -ds;
+  const v2f e0 = __builtin_elementwise_fma(nds, r, v2_splat(1.f));
+  const v2f r1 = __builtin_elementwise_fma(e0, r, r);
+  const v2f q0 = ns * r1;
+  const v2f e1 = __builtin_elementwise_fma(nds, q0, ns);
+  const v2f q1 = __builtin_elementwise_fma(e1, r1, q0);
+  const v2f e2 = __builtin_elementwise_fma(nds, q1, ns);
+  v2f q;
+  q.x = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.x, r1.x, q1.x, f0), b.x, a.x);
+  q.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.y, r1.y, q1.y, f1), b.y, a.y);
+  return q;
+}
+// sdf_update for a pair of slices (se_sdf_apply_nb twice): returns the two `upd` flags in bits 0 / 1
+__device__ __forceinline__ unsigned se_sdf_apply_nb2(const IntegArgs& a, bool valid0, bool valid1, v2f depthSample, v2f posx, v2f posy, v2f posz, v2f& vx, v2f& vy) {
+  const v2f qx = se_div2(posx, posz), qy = se_div2(posy, posz);
+  const v2f s = (v2_splat(1.f) + qx * qx) + qy * qy;
+  const v2f root = {sqrtf(s.x), sqrtf(s.y)};
+  const v2f diff = (depthSample - posz) * root;
+  const bool upd0 = valid0 && !(depthSample.x <= 0) && (diff.x > -a.mu);
+  const bool upd1 = valid1 && !(depthSample.y <= 0) && (diff.y > -a.mu);
+  const v2f quot = se_div2(diff, v2_splat(a.mu));
+  const v2f sdf = {fminf(1.f, quot.x), fminf(1.f, quot.y)};
+  const v2f avg = se_div2(vy * vx + sdf, vy + v2_splat(1.f));
+  const v2f yn = vy + v2_splat(1.f);
+  vx.x = upd0 ? clampf(avg.x, -1.f, 1.f) : vx.x;
+  vx.y = upd1 ? clampf(avg.y, -1.f, 1.f) : vx.y;
+  vy.x = upd0 ? fminf(yn.x, a.maxweight) : vy.x;
+  vy.y = upd1 ? fminf(yn.y, a.maxweight) : vy.y;
+  return (upd0 ? 1u : 0u) | (upd1 ? 2u : 0u);
+}
 // Branch-free forms for the block sweep: every expression of the functor is evaluated for every lane
 // (results of lanes that the reference skips are discarded by the final selects), so that the 8
 // z-slices of a lane are 8 independent dependency chains the compiler can interleave -- the sweep is
@@ -704,8 +758,16 @@ __device__ __forceinline__ void se_update_node_corner(const DevMap& m, const flo
 // 512^3 / 1024^3 / 2048^3 -- the sweep is bound by neither instruction count nor load width.
 // SHARD: the owner-computes variant (IntegArgs::shard_world > 1) -- a template parameter because its packing code costs the
 // plain sweep 11 VGPRs (91 -> 102: 4 waves per SIMD instead of 5, 128 -> 138 us at 1024^3).
+#ifndef SE_SWEEP_WAVES
+#define SE_SWEEP_WAVES 0    // > 0: force the register budget of that many waves per SIMD (the packed form needs 98 VGPRs: 5 -> 96 + 12 B of scratch)
+#endif
+#if SE_SWEEP_WAVES > 0
+#define SE_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(SE_SWEEP_WAVES, SE_SWEEP_WAVES)))
+#else
+#define SE_SWEEP_OCC
+#endif
 template <bool OFUSION, bool STATS, bool SHARD>
-__global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
+__global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * SE_WG + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * SE_WG) >> 6;
@@ -756,6 +818,59 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     const int y = by + ly;
     // update_block (projective_functor.hpp:73-111) in stages over the 8 z-slices of the lane, without
     // branches: each stage is 8 independent copies of the same short dependency chain.
+    bool upd[8];
+#if SE_SWEEP_PACKED
+    if (!OFUSION) {
+      // the part of R * p that does not depend on z, and the per-lane x offsets (the scalar code's own subexpressions)
+      const float px_ = bx * a.voxel, py_ = y * a.voxel;
+      const float hx = a.R[0] * px_ + a.R[1] * py_, hy = a.R[3] * px_ + a.R[4] * py_, hz = a.R[6] * px_ + a.R[7] * py_;
+      const float cdx = fx * a.cdelta[0], cdy = fx * a.cdelta[1], cdz = fx * a.cdelta[2];
+      const float ddx = fx * a.delta[0], ddy = fx * a.delta[1], ddz = fx * a.delta[2];
+      // two halves of two slice pairs each: the projected positions of only four slices are alive across the depth gathers
+      // (all eight: 102 VGPRs = 4 waves per SIMD instead of 5)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        v2f posx[2], posy[2], posz[2], dsp[2];
+        int pidx[4];
+        bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k2 = 2 * half + j;
+          const v2f pz = {(bz + 2 * k2) * a.voxel, (bz + 2 * k2 + 1) * a.voxel};
+          const v2f sx = (v2_splat(hx) + a.R[2] * pz) + v2_splat(a.t[0]);
+          const v2f sy = (v2_splat(hy) + a.R[5] * pz) + v2_splat(a.t[1]);
+          const v2f sz = (v2_splat(hz) + a.R[8] * pz) + v2_splat(a.t[2]);
+          const v2f csx = (a.K3[0] * sx + a.K3[1] * sy) + a.K3[2] * sz;
+          const v2f csy = (a.K3[3] * sx + a.K3[4] * sy) + a.K3[5] * sz;
+          const v2f csz = (a.K3[6] * sx + a.K3[7] * sy) + a.K3[8] * sz;
+          const v2f cvx = csx + v2_splat(cdx), cvy = csy + v2_splat(cdy), cvz = csz + v2_splat(cdz);
+          posx[j] = sx + v2_splat(ddx); posy[j] = sy + v2_splat(ddy); posz[j] = sz + v2_splat(ddz);
+          const v2f inverse_depth = se_div2(v2_splat(1.f), cvz);
+          const v2f pixx = cvx * inverse_depth + v2_splat(0.5f);
+          const v2f pixy = cvy * inverse_depth + v2_splat(0.5f);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float pzv = e ? posz[j].y : posz[j].x, pxx = e ? pixx.y : pixx.x, pyy = e ? pixy.y : pixy.x;
+            const bool v = !(pzv < 0.0001f) && !(pxx < 0.5f || pxx > a.W - 1.5f || pyy < 0.5f || pyy > a.H - 1.5f);
+            valid[2 * j + e] = v;
+            visible = visible || v;
+            pidx[2 * j + e] = v ? cvt_i32(pxx) + a.W * cvt_i32(pyy) : 0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dsp[j] = (v2f){depthmap[pidx[2 * j]], depthmap[pidx[2 * j + 1]]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k2 = 2 * half + j;
+          v2f x2 = {vx[2 * k2], vx[2 * k2 + 1]}, y2 = {vy[2 * k2], vy[2 * k2 + 1]};
+          const unsigned u = se_sdf_apply_nb2(a, valid[2 * j], valid[2 * j + 1], dsp[j], posx[j], posy[j], posz[j], x2, y2);
+          vx[2 * k2] = x2.x; vx[2 * k2 + 1] = x2.y; vy[2 * k2] = y2.x; vy[2 * k2 + 1] = y2.y;
+          upd[2 * k2] = (u & 1u) != 0u; upd[2 * k2 + 1] = (u & 2u) != 0u;
+        }
+      }
+    } else
+#endif
+    {
     f3 pos[8];
     int pidx[8];
     bool valid[8];
@@ -776,7 +891,6 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
     }
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) ds[zi] = depthmap[pidx[zi]];
-    bool upd[8];
 #ifdef SE_FAST_DIV_MU
     if (!OFUSION && a.inv_mu != 0.f) {
 #pragma unroll
@@ -787,6 +901,7 @@ __global__ __launch_bounds__(SE_WG) void k_integrate(DevMap m, const float* __re
 #pragma unroll
       for (int zi = 0; zi < 8; ++zi)
         upd[zi] = OFUSION ? se_bfusion_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]) : se_sdf_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
+    }
     }
     // a voxel the functor left alone is written back unchanged only if a neighbour in the same 256-byte
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
