@@ -36,11 +36,7 @@
 #endif
 #define SE_MAX_LEVELS 12
 
-enum { C_BLOCKS = 0, C_NODES = 1, C_OVERFLOW = 2, C_SNAP = 3, C_COUNT = 8 };   // C_SNAP: block count when the last sweep started (every allocation of its frame done)
-// bactive[] values.  At rest only 0 / 1 (VoxelBlock::active_).  The other two exist only inside a frame whose allocation scan runs
-// BESIDE its sweep (closed-loop schedule, se_hip_api.hip): 2 = swept this frame by the first sweep pass and left inactive,
-// 3 = to be swept by the second pass (allocated this frame, or hit by a ray of the scan while inactive).
-enum { BA_INACTIVE = 0, BA_ACTIVE = 1, BA_DONE_INACTIVE = 2, BA_PENDING_SWEEP = 3 };
+enum { C_BLOCKS = 0, C_NODES = 1, C_OVERFLOW = 2, C_COUNT = 8 };
 enum { S_PROBES = 0, S_NEWKEYS = 1, S_SWEPT = 2, S_NODES = 3, S_GETS = 4, S_INTERPS = 5, S_GRADS = 6, S_HITS = 7,
        S_T_ITER = 8, S_T_MARCH = 9, S_T_GRAD = 10, S_T_WAVEMAX = 11, S_T_STAGE = 12, S_COUNT = 16 };
 
@@ -51,7 +47,6 @@ struct DevMap {
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
-  int flag_new;                   // bactive value of a block this launch allocates: BA_ACTIVE, or BA_PENDING_SWEEP when the scan runs beside the sweep
   uint32_t leaf_off;              // = off[leaf_level]; kept separately so that hot kernels never index off[] dynamically
   float dim;
   float* vx;

@@ -103,12 +103,6 @@ struct se_hip_pipeline {
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool scan_on_side = false;   // stream the LAST allocation scan ran on: se_hip_alloc_exchange / se_hip_alloc_commit follow it
-  // Closed-loop schedule (r03): when se_hip_integrate finds the main stream idle -- a caller that synchronises every frame -- the
-  // scan goes to the scan stream and the sweep runs beside it in two passes (IntegArgs::phase): scan || pass 1, then pass 2.
-  bool closed_overlap = true;  // SE_HIP_CLOSED_OVERLAP=0: the serial scan -> sweep of r02 instead
-  bool want_concurrent = false;   // set by se_hip_integrate around its se_hip_alloc_scan call (the sweep is guaranteed to follow)
-  bool scan_concurrent = false;   // the scan just enqueued runs beside pass 1 of its sweep
-  bool snap_valid = true;      // ctr[C_SNAP] is the current block count (no allocation since the last sweep started)
   bool upload_on_side = false; // the current depth image was uploaded on `side`
   const float* scaled0 = nullptr;   // scaled_depth_[0] of the last se_hip_track
   // direct RCCL exchange of the key lists (se_hip_set_exchange): the caller's communicator and ncclAllGather
@@ -251,11 +245,9 @@ void make_logodds(const std::vector<float>& lut, std::vector<float>& tab) {
     }
 }
 
-int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlists, long long stride_words, int flag_new = BA_ACTIVE) {
+int run_zero_chain(se_hip_pipeline* p, const unsigned long long* lists, int nlists, long long stride_words) {
   ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
-  DevMap md = p->map;
-  md.flag_new = flag_new;
-  hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(SE_WG), 0, p->stream, md, lists, nlists, stride_words);
+  hipLaunchKernelGGL(k_zero_chain, dim3(1), dim3(SE_WG), 0, p->stream, p->map, lists, nlists, stride_words);
   return SE_HIP_OK;
 }
 
@@ -460,7 +452,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
 #endif
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
-  if (const char* ev = std::getenv("SE_HIP_CLOSED_OVERLAP")) p->closed_overlap = std::atoi(ev) != 0;   // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
     int a = 0, b = 0, c = 0;
     if (std::sscanf(ev, "%d,%d,%d", &a, &b, &c) == 3 && a >= b && b >= c && c >= 0 && a <= 1000) { p->prio_permille[0] = a; p->prio_permille[1] = b; p->prio_permille[2] = c; }
@@ -469,7 +460,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->leaf_level = p->max_level - 3;
   DevMap& m = p->map;
   m.size = N; m.max_level = p->max_level; m.leaf_level = p->leaf_level; m.dim = cfg->volume_dimension;
-  m.flag_new = BA_ACTIVE;
   size_t off = 0;
   for (int l = 0; l < SE_MAX_LEVELS; ++l) m.off[l] = 0;
   for (int l = 1; l <= p->leaf_level; ++l) { m.off[l] = (uint32_t)off; off += (size_t)1 << (3 * l); }
@@ -767,21 +757,12 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   // se_hip_set_exchange): whoever consumes that list is told "scan stream" by se_hip_scan_overlaps().
   const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
   const bool ov = p->overlap && (p->sharded || caller_list || p->xgather != nullptr || hipStreamQuery(p->stream) == hipErrorNotReady);
-  // Closed-loop schedule: main stream idle (so every earlier frame is complete), plain single handle, called from
-  // se_hip_integrate: the scan goes to the scan stream and runs BESIDE the first pass of this frame's sweep, which takes exactly
-  // the blocks that were active before the frame (IntegArgs::phase); the scan leaves the flags of those alone (se_mark_active
-  // mode 2) and marks what it allocates or wakes for the second pass.
-  const bool conc = !ov && p->want_concurrent && p->closed_overlap && p->overlap && p->side && p->snap_valid && !p->sharded && !caller_list && !p->xgather && p->shard_world <= 1;
-  p->scan_concurrent = conc;
-  p->scan_on_side = ov || conc;
-  hipStream_t s = (ov || conc) ? p->side : p->stream;
+  p->scan_on_side = ov;
+  hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
-  ms.defer_occ = (ov || conc) ? 1 : 0;
-  ms.flag_new = conc ? BA_PENDING_SWEEP : BA_ACTIVE;
-  a.concurrent = conc ? 1 : 0;
+  ms.defer_occ = ov ? 1 : 0;
   if (ov) { if (p->host_gate) wait_last_sweep(p); else HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0)); }
-  else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here (conc: pass 1 of the sweep reads the image on the main stream)
-  if (conc) p->gate_armed = false;   // (main stream idle: the last sweep is long done)
+  else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here
   const bool own_list = p->map.newkeys == p->newkeys_own || p->map.newkeys == p->newkeys_own2;
   if (own_list) {
     // the own lists alternate; the previous frame's sweep kernel has already cleared this one's count word (no fill
@@ -813,7 +794,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
       else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
     }
   }
-  if (ov || conc) {
+  if (ov) {
     HIP_TRY(hipEventRecord(p->ev_scan, p->side));
     p->scan_pending = true;
     HIP_TRY(hipGetLastError());
@@ -848,7 +829,6 @@ int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_
   if (int r = check(p)) return r;
   if (!device_lists || nlists <= 0 || stride_words < 1) return fail(SE_HIP_E_INVALID, "bad argument");
   const unsigned long long* lists = (const unsigned long long*)device_lists;
-  p->snap_valid = false;    // blocks are inserted outside a scan -> sweep pair: ctr[C_SNAP] is stale until the next sweep
   if (p->overlap && p->side && p->scan_on_side) {
     // The gathered lists were produced on the scan stream (scan kernel, then the caller's all-gather ordered
     // behind it).  The insertion of the peers' keys stays on that stream -- beside the previous frame's raycast,
@@ -938,9 +918,7 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!stage_runs_integration(frame, rate)) return 0;
   if (int r = check_overflow(p)) return r;
-  const bool conc = p->scan_concurrent && p->scan_pending;   // closed-loop schedule: the scan is running on the scan stream right now
-  p->scan_concurrent = false;
-  if (!conc) { if (int r = join_scan(p, true)) return r; }
+  if (int r = join_scan(p, true)) return r;
   const DevMap& m = p->map;
   const M4 pose = from_colmajor(pose_cm);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
@@ -1030,42 +1008,18 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
     const size_t wgs = std::min<size_t>(std::max<size_t>((est + 3) / 4, 2048), 65536);
     const dim3 grid(p->integ_grid > 0 ? (unsigned)p->integ_grid : (unsigned)wgs);
 #define SE_SWEEP(OF, ST, SHD) hipLaunchKernelGGL((k_integrate<OF, ST, SHD>), grid, block, 0, p->stream, m, p->depth, a)
-    auto launch = [&]() {
-      switch ((sdf ? 0 : 4) | (p->stats ? 2 : 0) | (a.shard_world > 1 ? 1 : 0)) {
-        case 0: SE_SWEEP(false, false, false); break;
-        case 1: SE_SWEEP(false, false, true); break;
-        case 2: SE_SWEEP(false, true, false); break;
-        case 3: SE_SWEEP(false, true, true); break;
-        case 4: SE_SWEEP(true, false, false); break;
-        case 5: SE_SWEEP(true, false, true); break;
-        case 6: SE_SWEEP(true, true, false); break;
-        case 7: SE_SWEEP(true, true, true); break;
-      }
-    };
-    if (!conc) {
-      a.phase = 0;
-      launch();
-    } else {
-      // pass 1, beside the scan: the blocks that were active before the frame; no counters, no occupancy bits, no nodes yet
-      IntegArgs full = a;
-      a.phase = 1; a.commit_occ = 0; a.occ_lists = OccLists{nullptr, 0, 0}; a.ctr_mirror = nullptr;
-      launch();
-      // the scan has to be complete from here on: its blocks, its wake-ups, its nodes, its key list
-      HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0));
-      p->scan_pending = false;
-      p->upload_on_side = false;
-      if (!sdf) { if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1, BA_PENDING_SWEEP)) return r; }   // keys[0] quirk: what it inserts is swept by pass 2
-      // pass 2: everything else, then the node corners; publishes the occupancy bits of the frame's key list and the counters
-      a = full;
-      a.phase = 2; a.commit_occ = 1; a.occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
-      a.zero_count = nullptr; a.prio_thr = nullptr; a.tile_cost = nullptr; a.ray_order = nullptr;
-      launch();
-      p->occ_commit_due = false;
-      p->occ_lists = OccLists{nullptr, 0, 0};
+    switch ((sdf ? 0 : 4) | (p->stats ? 2 : 0) | (a.shard_world > 1 ? 1 : 0)) {
+      case 0: SE_SWEEP(false, false, false); break;
+      case 1: SE_SWEEP(false, false, true); break;
+      case 2: SE_SWEEP(false, true, false); break;
+      case 3: SE_SWEEP(false, true, true); break;
+      case 4: SE_SWEEP(true, false, false); break;
+      case 5: SE_SWEEP(true, false, true); break;
+      case 6: SE_SWEEP(true, true, false); break;
+      case 7: SE_SWEEP(true, true, true); break;
     }
 #undef SE_SWEEP
   }
-  p->snap_valid = true;    // the launch above wrote ctr[C_SNAP]
   // the next frame's scan / depth upload may start behind this point: an event for the scan stream to wait on, or (host
   // gate) the sequence number of the raycast that follows
   if (p->host_gate) { p->gate_armed = true; p->gate_followed = false; p->gate_target = p->ray_seq + 1u; }
@@ -1075,10 +1029,8 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
 }
 
 int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
-  if (p) p->want_concurrent = true;     // scan and sweep in one call: the closed-loop schedule may run them side by side
   int r = se_hip_alloc_scan(p, pose, k, rate, mu, frame);
-  if (p) p->want_concurrent = false;
-  if (r <= 0) { if (p) p->scan_concurrent = false; return r; }
+  if (r <= 0) return r;
   return se_hip_integrate_sweep(p, pose, k, rate, mu, frame);
 }
 
@@ -1669,9 +1621,8 @@ int se_hip_load_map(se_hip_pipeline* p, const char* filename) {
   // everything that can fail without touching the map has succeeded: quiesce, re-initialise, insert
   if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
   HIP_TRY(hipStreamSynchronize(p->stream));
-  p->scan_pending = false; p->scan_concurrent = false; p->occ_commit_due = false; p->occ_lists = OccLists{nullptr, 0, 0};
+  p->scan_pending = false; p->occ_commit_due = false; p->occ_lists = OccLists{nullptr, 0, 0};
   reset_map_state(p);
-  p->snap_valid = false;    // the blocks of the file are inserted below, outside a scan -> sweep pair
   hipMemcpyAsync(d_list, list.data(), list.size() * 8, hipMemcpyHostToDevice, p->stream);
   hipLaunchKernelGGL(k_alloc_commit, dim3(256, 1), dim3(SE_WG), 0, p->stream, p->map, d_list, 1, (long long)list.size());
   if (nn) {

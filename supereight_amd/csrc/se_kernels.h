@@ -65,7 +65,7 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
     const uint32_t bp = pack_pos(x, y, z);
     const uint32_t slot = block_slot(m, idx, bp);
     m.bpos[idx] = bp;
-    m.bactive[slot] = (uint8_t)m.flag_new;  // allocate_level: active(true), octree.hpp:841 (BA_PENDING_SWEEP: active, and not swept yet, see se_device.h)
+    m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
     occ_set(m, level, x, y, z);
     atomicExch(e, slot + 1u);
   } else {
@@ -94,25 +94,8 @@ __device__ __forceinline__ bool se_set_active_once(const DevMap& m, uint32_t slo
   const uint32_t bit = 1u << (8u * (slot & 3u));
   return (atomicOr(w, bit) & (0xFFu << (8u * (slot & 3u)))) == 0u;
 }
-// n->active(true) when the scan runs BESIDE the first pass of its frame's sweep (closed-loop schedule): that pass reads and
-// writes the flags of the blocks that were active before the frame, so the scan must leave those alone -- whatever it could
-// tell them is moot, they are swept anyway.  A block that is inactive (0) goes 0 -> BA_PENDING_SWEEP, which the second sweep
-// pass picks up; a block the first pass has already swept and left inactive (2) stays: the reference would sweep it once too,
-// with the same data, and end with the same flag.  Byte-wide compare-and-swap on the containing word (the first pass stores
-// other bytes of the same word concurrently: a changed neighbour only makes the CAS retry).
-__device__ __forceinline__ void se_wake_block(const DevMap& m, uint32_t slot) {
-  uint32_t* w = (uint32_t*)m.bactive + (slot >> 2);
-  const uint32_t sh = 8u * (slot & 3u);
-  uint32_t old = *(volatile uint32_t*)w;
-  while (((old >> sh) & 0xFFu) == (uint32_t)BA_INACTIVE) {
-    const uint32_t seen = atomicCAS(w, old, old | ((uint32_t)BA_PENDING_SWEEP << sh));
-    if (seen == old) break;
-    old = seen;
-  }
-}
-__device__ __forceinline__ void se_mark_active(const DevMap& m, uint32_t slot, int mode /*0 plain, 1 row-sharded, 2 beside the sweep*/, int bx, int by, int bz) {
-  if (mode == 2) se_wake_block(m, slot);
-  else if (mode == 1) { if (se_set_active_once(m, slot)) se_append_key(m, m.leaf_level, bx, by, bz, SE_KEY_ACTIVATE); }   // one key per block, not one per ray
+__device__ __forceinline__ void se_mark_active(const DevMap& m, uint32_t slot, bool sharded, int bx, int by, int bz) {
+  if (sharded) { if (se_set_active_once(m, slot)) se_append_key(m, m.leaf_level, bx, by, bz, SE_KEY_ACTIVATE); }   // one key per block, not one per ray
   else m.bactive[slot] = 1;
 }
 
@@ -134,7 +117,6 @@ struct AllocArgs {
   int W, H, row_begin, row_end;
   int depth_fine, depth_mid, depth_coarse;  // OFusion: step_to_depth() of the three step sizes
   int sharded;      // this replica scans only part of the image: report re-activated blocks to the peers
-  int concurrent;   // the scan runs beside the first pass of this frame's sweep (se_mark_active mode 2)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -183,7 +165,8 @@ __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& 
     } else if (e != SE_PENDING) {
       // n->active(true), alloc_impl.hpp:109.  A row-sharded replica only sees its own rays, so a block it
       // switches from inactive to active is also reported to the peers -- once, by the thread that flipped it.
-      se_mark_active(m, e - 1u, a.concurrent ? 2 : (a.sharded ? 1 : 0), bx, by, bz);
+      if (a.sharded) { if (se_set_active_once(m, e - 1u)) se_append_key(m, L, bx, by, bz, SE_KEY_ACTIVATE); }
+      else m.bactive[e - 1u] = 1;
     }
   }
 }
@@ -317,7 +300,7 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, con
             if (e == 0u) {
               if (se_insert_octant(m, lvl, ox, oy, oz)) { se_append_key(m, lvl, ox, oy, oz); ++newk; }
             } else if (tree_depth >= m.leaf_level && e != SE_PENDING) {
-              se_mark_active(m, e - 1u, a.concurrent ? 2 : (a.sharded ? 1 : 0), ox, oy, oz);
+              se_mark_active(m, e - 1u, a.sharded != 0, ox, oy, oz);
             }
           }
         }
@@ -470,11 +453,6 @@ struct IntegArgs {
   int W, H;
   const float* bspline;    // OFusion: 1000-entry B-spline CDF table
   const float* logodds;    // OFusion: log2f(s/(1-s)) for every (Q1 index, Q2 index) pair, see se_hip_api.hip
-  int phase;               // 0: the whole sweep in one launch.  Closed-loop schedule (the allocation scan runs BESIDE the sweep):
-                           // 1 = first pass, beside the scan: exactly the blocks that were active before the frame (flag 1; they are swept
-                           //     whatever the scan finds), among the C_SNAP blocks that existed then; leaves 1 (visible) or 2 (swept, inactive);
-                           // 2 = second pass, behind the scan: blocks allocated or hit by the scan (flag 3) and inactive ones in the frustum
-                           //     (flag 0), turns 2 back into 0, then the node corners (new nodes included)
   int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan / commit first
   OccLists occ_lists;      // the key lists whose insertions are published
 #ifdef SE_DIAG
@@ -793,10 +771,8 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * SE_WG + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * SE_WG) >> 6;
-  const uint32_t nblocks = min(a.phase == 1 ? m.ctr[C_SNAP] : m.ctr[C_BLOCKS], m.cap_blocks);
-  const uint32_t nnodes = a.phase == 1 ? 0u : min(m.ctr[C_NODES], m.cap_nodes);
-  // the block count every allocation of this frame has gone into: what the first pass of the NEXT frame's sweep may touch
-  if (a.phase != 1 && blockIdx.x == 0 && threadIdx.x == 0) m.ctr[C_SNAP] = nblocks;
+  const uint32_t nblocks = min(m.ctr[C_BLOCKS], m.cap_blocks);
+  const uint32_t nnodes = min(m.ctr[C_NODES], m.cap_nodes);
   const int lx = lane & 7, ly = lane >> 3;
   const float fx = (float)lx;
   unsigned long long swept = 0;
@@ -816,16 +792,7 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
     if (SHARD && (unsigned)((bx >> 3) + (by >> 3) + (bz >> 3)) % (unsigned)a.shard_world != (unsigned)a.shard_rank) continue;
     const uint32_t slot = block_slot(m, b, bp);
-    const uint32_t flag = m.bactive[slot];
-    if (a.phase == 0) {
-      if (!flag && !se_in_frustum(a, bx, by, bz)) continue;     // build_active_list: active || in_frustum
-    } else if (a.phase == 1) {
-      if (flag != (uint32_t)BA_ACTIVE) continue;
-    } else {
-      if (flag == (uint32_t)BA_ACTIVE) continue;                                                              // swept by the first pass, visible
-      if (flag == (uint32_t)BA_DONE_INACTIVE) { if (lane == 0) m.bactive[slot] = BA_INACTIVE; continue; }     // swept by the first pass, not visible
-      if (flag == (uint32_t)BA_INACTIVE && !se_in_frustum(a, bx, by, bz)) continue;
-    }
+    if (!m.bactive[slot] && !se_in_frustum(a, bx, by, bz)) continue;
     if (STATS && lane == 0) ++swept;
     float* px = m.vx + (size_t)slot * SE_BRICK_STRIDE + lane;
     float* py = m.vy + (size_t)slot * SE_BRICK_STRIDE + lane;
@@ -946,7 +913,7 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
       if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
     const bool any = __ballot(visible) != 0ull;
-    if (lane == 0) m.bactive[slot] = any ? BA_ACTIVE : (a.phase == 1 ? BA_DONE_INACTIVE : BA_INACTIVE);  // block->active(is_visible)
+    if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
     if (SHARD) {   // the other replicas get this block's flag and, if anything of it was in view, its voxels
       // record slots are handed out by SE_SHARD_SUB counters, each over its own 1/SE_SHARD_SUB of the segment (one
       // counter for the ~10 k blocks of a frame is 50-70 us of serialised atomics: one word takes ~90 of them per us)
