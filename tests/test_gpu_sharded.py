@@ -13,14 +13,36 @@ from supereight_amd.synthetic import SyntheticStream
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("field,mu,R,H", [(SDF, 0.1, 2, 120), (SDF, 0.1, 4, 120), (OFUSION, 0.02, 2, 120), (SDF, 0.1, 8, 116), (OFUSION, 0.02, 8, 116)],
-                         ids=["sdf-2", "sdf-4", "ofusion-2", "sdf-8-odd-height", "ofusion-8-odd-height"])
+@pytest.mark.parametrize("field,mu,R,H", [(SDF, 0.1, 2, 120), (SDF, 0.1, 4, 120), (OFUSION, 0.02, 2, 120), (SDF, 0.1, 8, 116), (OFUSION, 0.02, 8, 116),
+                                          (SDF, 0.1, 4, -120), (OFUSION, 0.02, 3, -120)],
+                         ids=["sdf-2", "sdf-4", "ofusion-2", "sdf-8-odd-height", "ofusion-8-odd-height", "sdf-4-stress", "ofusion-3-stress"])
 def test_sharded_replicas_equal_single(field, mu, R, H):
     # H = 116: 14.5 raycast tiles of 8 rows -> shards of 1 or 2 tile rows, the last one ending in a half tile
+    # H < 0: the ICL-like stress stream (r03), every 3rd frame of its path: blocks leave the frustum of one rank's rows and are woken
+    # by another rank's rays, hundreds of new keys per frame and rank, samples outside the volume
     import torch
     W, N, dim, frames = 160, 256, 2.4, 6
     dev = torch.device("cuda", 0)
-    stream = SyntheticStream(W, H, dim)
+    if H < 0:
+        from supereight_amd.synthetic import StressStream
+        H, frames, dim = -H, 24, 4.8
+
+        class _Every3rd:
+            def __init__(self):
+                self.s = StressStream(W, H, dim)
+                self.k = self.s.k
+
+            def depth(self, f):
+                d = None
+                for g in range(3 * f - 2 if f else 0, 3 * f + 1):
+                    d = self.s.depth(g)
+                return d
+
+            def pose(self, f):
+                return self.s.pose(3 * f)
+        stream = _Every3rd()
+    else:
+        stream = SyntheticStream(W, H, dim)
     single = DenseSLAMPipeline((W, H), N, dim, field_type=field)
     parts = row_partition(H, R)
     reps = [DenseSLAMPipeline((W, H), N, dim, field_type=field, rows=parts[r]) for r in range(R)]

@@ -73,8 +73,9 @@ def test_stress_stream_parity(name, field, W, H, N, mu, frames, max_blocks):
     gpu.close()
 
 
-@pytest.mark.parametrize("field,mu,frames", [(SDF, 0.1, 48), (OFUSION, 0.02, 40)], ids=["sdf", "ofusion"])
-def test_stress_stream_pipelined(field, mu, frames):
+@pytest.mark.parametrize("field,mu,frames,max_blocks", [(SDF, 0.1, 48, 0), (OFUSION, 0.02, 40, 0), (SDF, 0.1, 48, 1 << 15), (OFUSION, 0.02, 40, 1 << 15)],
+                         ids=["sdf", "ofusion", "sdf-pooled", "ofusion-pooled"])
+def test_stress_stream_pipelined(field, mu, frames, max_blocks):
     """The same stream enqueued back to back without synchronisation (scan of frame f+1 beside the raycast of frame f,
     alternating key lists, occupancy bits published by the sweep): final map and last raycast bit-exact."""
     import torch
@@ -86,7 +87,9 @@ def test_stress_stream_pipelined(field, mu, frames):
     depths = [s.depth(f) for f in range(frames)]
     poses = [s.pose(f) for f in range(frames)]
     dev = torch.from_numpy(np.stack(depths)).cuda()
-    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field)
+    # pooled bricks (r03): their raycast reads the index that the next frame's scan, running beside it, is writing (se_block_entry)
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field, max_blocks=max_blocks)
+    assert gpu.scan_overlaps()
     k = np.ascontiguousarray(s.k, np.float32)
     for f in range(frames):
         gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)
