@@ -1197,7 +1197,8 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     InvK ik;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) ik.m[r * 4 + c] = invK.m[r][c];
     const float* dsrc = i == 0 ? d0 : p->pyr_depth[i];
-    hipLaunchKernelGGL(k_vertex_normal, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_vertex[i], p->pyr_normal[i], dsrc, w, h, ik, k[1] < 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_depth2vertex, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_vertex[i], dsrc, w, h, ik);
+    hipLaunchKernelGGL(k_vertex2normal, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_normal[i], p->pyr_vertex[i], w, h, k[1] < 0 ? 1 : 0);
   }
   // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, each
   // two launches (k_icp_track: trackKernel + reduceKernel's partial sums; k_icp_update: final sums + updatePoseKernel); the pose, the convergence flags and the sums

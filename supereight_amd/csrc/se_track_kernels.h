@@ -90,38 +90,6 @@ __global__ void k_vertex2normal(float* __restrict__ out, const float* __restrict
   o[0] = n.x; o[1] = n.y; o[2] = n.z;
 }
 
-// depth2vertexKernel + vertex2normalKernel of one pyramid level in one launch: the normal of a pixel needs the vertices of its four
-// neighbours, which are recomputed from the depth image with depth2vertexKernel's own expression (identical values, no second
-// launch, no dependency on another thread's store).
-__device__ __forceinline__ f3 se_depth2vertex_at(const float* __restrict__ depth, int W, int x, int y, const InvK& K) {
-  const float d = depth[x + y * W];
-  f3 v = {0.f, 0.f, 0.f};
-  if (d > 0) {
-    v.x = (((d * K.m[0]) * (float)x + (d * K.m[1]) * (float)y) + (d * K.m[2]) * 1.f) + (d * K.m[3]) * 0.f;
-    v.y = (((d * K.m[4]) * (float)x + (d * K.m[5]) * (float)y) + (d * K.m[6]) * 1.f) + (d * K.m[7]) * 0.f;
-    v.z = (((d * K.m[8]) * (float)x + (d * K.m[9]) * (float)y) + (d * K.m[10]) * 1.f) + (d * K.m[11]) * 0.f;
-  }
-  return v;
-}
-__global__ void k_vertex_normal(float* __restrict__ vertex, float* __restrict__ normal, const float* __restrict__ depth, int width, int height, InvK K, int negy) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= width || y >= height) return;
-  const f3 center = se_depth2vertex_at(depth, width, x, y, K);
-  float* v = vertex + 3 * (size_t)(x + y * width);
-  v[0] = center.x; v[1] = center.y; v[2] = center.z;
-  float* o = normal + 3 * (size_t)(x + y * width);
-  if (center.z == 0.f) { o[0] = -2.f; return; }
-  const int plx = max(x - 1, 0), prx = min(x + 1, width - 1);
-  int puy, pdy;
-  if (negy) { puy = max(y - 1, 0); pdy = min(y + 1, height - 1); }
-  else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
-  const f3 left = se_depth2vertex_at(depth, width, plx, y, K), right = se_depth2vertex_at(depth, width, prx, y, K);
-  const f3 up = se_depth2vertex_at(depth, width, x, puy, K), down = se_depth2vertex_at(depth, width, x, pdy, K);
-  if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
-  const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
-  o[0] = n.x; o[1] = n.y; o[2] = n.z;
-}
-
 struct TrackArgs {
   float view[12];  // K * raycast_pose^-1, rows 0..2
   float dist_threshold, normal_threshold;
@@ -298,7 +266,7 @@ __global__ void k_icp_begin(IcpState* s, Pose16 pose) {
 //    reference leaves the summation order of the reduction to OpenMP; here (and in the oracle) it is fixed: strip b = rows
 //    y = b (mod 8) as in the reference, split into SE_TRACK_SEGMENTS contiguous segments, one workgroup each; lane t computes the
 //    TrackData of pixels t, t+256, ... of its segment and accumulates them in that order; the 256 partials are combined by a
-//    binary tree inside each group of 64 lanes (stride 32, 16, ... 1) and the four group sums are then added in order.
+//    binary tree.
 //  k_icp_update = the rest of reduceKernel + updatePoseKernel (tracking.cpp:205-224, 304-318): per strip the segments are added in
 //    order (8 x 32 lanes in parallel), then the strips in order; one lane solves the 6x6 system, applies exp(x) to the pose and
 //    evaluates the convergence test, all in the oracle's order; pose, flags and sums stay in device memory for the next launch.
@@ -308,7 +276,7 @@ __global__ void k_icp_begin(IcpState* s, Pose16 pose) {
 __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __restrict__ s, const float* __restrict__ inVertex,
                                                                const float* __restrict__ inNormal, const float* __restrict__ refVertex,
                                                                const float* __restrict__ refNormal, float* __restrict__ partial, TrackArgs a) {
-  __shared__ float wsum[SE_TRACK_LANES / 64][32];
+  __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
   if (s->stop[a.level]) return;                 // the level has converged: the reference's `break` (set by an earlier launch only)
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
   float T[12];
@@ -331,17 +299,16 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __
     se_track_pixel(row, x, y, inVertex, inNormal, refVertex, refNormal, T, a);
     se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_rows)
   }
-  // the 256 partials: a binary tree inside each wave (lane l += lane l + 32, + 16, ... + 1: registers only), then the four waves in
-  // order
 #pragma unroll
-  for (int st = 32; st > 0; st >>= 1)
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] += __shfl_down(acc[i], st);
-  if ((t & 63) == 0)
-#pragma unroll
-    for (int i = 0; i < 32; ++i) wsum[t >> 6][i] = acc[i];
+  for (int i = 0; i < 32; ++i) lanes[t][i] = acc[i];
   __syncthreads();
-  if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
+  for (int st = SE_TRACK_LANES / 2; st > 0; st >>= 1) {
+    if (t < st)
+#pragma unroll
+      for (int i = 0; i < 32; ++i) lanes[t][i] += lanes[t + st][i];
+    __syncthreads();
+  }
+  if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = lanes[0][t];
 }
 
 __global__ __launch_bounds__(256) void k_icp_update(IcpState* __restrict__ s, const float* __restrict__ partial, TrackArgs a) {
