@@ -32,6 +32,9 @@
                         // every lane of a wave in which any lane is in that state, and half of them are fetched past the end of the walk.
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
+#ifndef SE_FIRST_LEAF_LITE
+#define SE_FIRST_LEAF_LITE 1   // raycast: stack-free first-leaf search (se_first_leaf_lite); 0 = the iterator with its LDS stack for every ray
+#endif
 
 // ------------------------------------------------------------------------------------------
 // index insertion (replaces Octree::allocate / allocate_level, se_core/include/se/octree.hpp:792-856)
@@ -1427,6 +1430,116 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   return {t_min * m.dim, tmax_m, guard};
 }
 
+// The same iterator without its stack (r04).  For a ray that is regular at set-up (it enters the volume before it
+// leaves it, nothing is NaN) the reference's stack of (parent, t_max) and its `h` carry no information
+// (tests/cpp/first_leaf_equiv.cpp is the CPU model of this function, checked ray by ray against the oracle's iterator):
+//  * parent: heap codes are child = parent * 8 + idx, so the node a pop returns to is the current code shifted right
+//    by three bits per level popped;
+//  * t_max = min(far / dim, root exit, tc_max of every ancestor cell on the path).  t = pos * t_coef - t_bias is
+//    monotone in pos, so every ancestor's tc_max is >= the tc_max of any cell inside it, and t_min only ever takes the
+//    tc_max of cells inside the current ancestors: `t_min <= t_max` is `t_min <= min(far / dim, root exit)` -- unless the
+//    ray descended from a cell whose own tc_max was already below t_min.  That does happen, once in ~10^6 rays: the child
+//    slot is chosen by t_center = half * t_coef + t_corner, a different rounding of the same plane than the child's own
+//    t_corner, so a ray within an ulp of a cell edge can be put into a child it has, by t_corner, already left.  Exactly
+//    that event (descent with tc_max < t_min) sets `redo`, as does an irregular set-up, and the caller re-runs those
+//    rays through se_first_leaf above (whole waves skip it: __any);
+//  * h only decides whether a slot is rewritten; a slot that is read was written by the first descent below the same
+//    parent (monotonicity again: a cell whose exit equals its parent's exit is left together with the parent).
+// What a trip then needs from memory is the 8 sibling bits of the current parent (byte `parent` of the heap-ordered
+// occupancy bits): one LDS byte per descent or pop instead of a word per trip; leaf parents take theirs from the 64
+// leaf bits of their own parent, fetched one level earlier as before.
+template <bool SHALLOW, typename Hook = SeNoHook>
+__device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const RayArgs& a, f3 origin, f3 direction, const uint32_t* s_occ,
+                                                      bool& redo, Hook before_loop = Hook(), bool live = true) {
+  f3 pos = {1.0f, 1.0f, 1.0f};
+  uint32_t parent = 1u;  // root
+  float scale_exp2 = 0.5f;
+  int scale = 22;
+  const float eps = a.epsilon;
+  f3 d;
+  d.x = fabsf(direction.x) < eps ? copysignf(eps, direction.x) : direction.x;
+  d.y = fabsf(direction.y) < eps ? copysignf(eps, direction.y) : direction.y;
+  d.z = fabsf(direction.z) < eps ? copysignf(eps, direction.z) : direction.z;
+  const f3 scaled_origin = {a.scaled_origin[0], a.scaled_origin[1], a.scaled_origin[2]};
+  const f3 t_coef = f3_scale(-1.f, {1.f / fabsf(d.x), 1.f / fabsf(d.y), 1.f / fabsf(d.z)});
+  f3 t_bias = f3_mul(t_coef, scaled_origin);
+  uint32_t om = 0u;     // octant_mask ^ 7
+  if (d.x > 0.0f) { om ^= 1u; t_bias.x = 3.0f * t_coef.x - t_bias.x; }
+  if (d.y > 0.0f) { om ^= 2u; t_bias.y = 3.0f * t_coef.y - t_bias.y; }
+  if (d.z > 0.0f) { om ^= 4u; t_bias.z = 3.0f * t_coef.z - t_bias.z; }
+  float t_min = fmaxf(fmaxf(2.0f * t_coef.x - t_bias.x, 2.0f * t_coef.y - t_bias.y), 2.0f * t_coef.z - t_bias.z);
+  const float h0 = fminf(fminf(t_coef.x - t_bias.x, t_coef.y - t_bias.y), t_coef.z - t_bias.z);
+  t_min = fmaxf(t_min, a.near_n);
+  const float t_lim = fminf(h0, a.far_n);   // t_max_init: all the t_max this loop knows
+  const float tmax_m = t_lim * m.dim;
+  redo = live && !(t_min < h0);             // irregular set-up (a ray that misses the volume, any NaN): full iterator
+  if (1.5f * t_coef.x - t_bias.x > t_min) pos.x = 1.5f;
+  if (1.5f * t_coef.y - t_bias.y > t_min) pos.y = 1.5f;
+  if (1.5f * t_coef.z - t_bias.z > t_min) pos.z = 1.5f;
+  const uint8_t* occ_bytes = (const uint8_t*)m.occ;
+  const uint8_t* s_occ8 = (const uint8_t*)s_occ;
+  const uint32_t staged_parents = a.cache_codes >> 3;   // parents below this code have their sibling byte in LDS
+  unsigned long long gp_bits = 0ull;   // the 64 leaf bits below the node two levels above the leaves the ray is in
+  uint32_t gp_code = 0u;
+  before_loop();
+  // sibling byte of parent P: staged -> LDS; leaf parent -> byte (P & 7) of gp_bits; else (volumes > 512^3) global
+#define SE_SIB_OF(P) ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)] : (uint32_t)occ_bytes[(P)])
+  uint32_t sib = s_occ8[1];   // the root's children: word 0 of the occupancy bits is always staged
+  int guard = 0;
+  const int max_trips = ((SE_DBG_PHASES(a) & 4) || !live || redo) ? 0 : 4096;
+  for (; guard < max_trips && scale < 23; ++guard) {
+    const f3 t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
+    const float tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
+    const uint32_t us = (uint32_t)scale;
+    const uint32_t ox = __float_as_uint(pos.x), oy = __float_as_uint(pos.y), oz = __float_as_uint(pos.z);
+    const uint32_t cidx = (__builtin_amdgcn_ubfe(ox, us, 1u) | (__builtin_amdgcn_ubfe(oy, us, 1u) << 1) | (__builtin_amdgcn_ubfe(oz, us, 1u) << 2)) ^ om;
+    const bool exists = (sib >> cidx) & 1u;
+    if (exists && scale == a.min_scale) break;   // leaf found: t_min is its entry distance
+    if (exists && t_min <= t_lim) {
+      if (tc_max < t_min) { redo = true; break; }
+      // descend (ray_iterator.hpp:172-199)
+      const float half = scale_exp2 * 0.5f;
+      const f3 t_center = f3_add(f3_scale(half, t_coef), t_corner);
+      pos.x += (t_center.x > t_min) ? half : 0.f;
+      pos.y += (t_center.y > t_min) ? half : 0.f;
+      pos.z += (t_center.z > t_min) ? half : 0.f;
+      parent = (parent << 3) | cidx;
+      scale -= 1;
+      scale_exp2 = half;
+      if (scale == a.min_scale && !(parent < staged_parents)) {   // entered a leaf parent
+        if ((parent >> 3) != gp_code) { gp_code = parent >> 3; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)gp_code << 3)); }
+        sib = (uint32_t)(gp_bits >> ((parent & 7u) << 3)) & 0xFFu;
+      } else {
+        if (scale == a.min_scale + 1) { gp_code = parent; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
+        sib = SE_SIB_OF(parent);
+      }
+    } else {
+      // advance_ray (ray_iterator.hpp:116-167)
+      pos.x -= (t_corner.x <= tc_max) ? scale_exp2 : 0.f;
+      pos.y -= (t_corner.y <= tc_max) ? scale_exp2 : 0.f;
+      pos.z -= (t_corner.z <= tc_max) ? scale_exp2 : 0.f;
+      t_min = tc_max;
+      const uint32_t differing_bits = (ox ^ __float_as_uint(pos.x)) | (oy ^ __float_as_uint(pos.y)) | (oz ^ __float_as_uint(pos.z));
+      if (differing_bits > (1u << us)) {
+        // pop: the highest differing bit is the scale of the first ancestor the ray is still inside
+        const int ns = 31 - __clz(differing_bits);
+        parent >>= 3 * (ns - scale);
+        scale = ns;
+        scale_exp2 = __int_as_float((scale - 23 + 127) << 23);
+        if (scale < 23) {
+          const uint32_t keep = 0xFFFFFFFFu << scale;
+          pos.x = __uint_as_float(__float_as_uint(pos.x) & keep);
+          pos.y = __uint_as_float(__float_as_uint(pos.y) & keep);
+          pos.z = __uint_as_float(__float_as_uint(pos.z) & keep);
+          sib = SE_SIB_OF(parent);
+        }
+      }
+    }
+  }
+#undef SE_SIB_OF
+  return {t_min * m.dim, tmax_m, guard};
+}
+
 // raycast(const Volume<T>&, origin, direction, tnear, tfar, mu, step, largestep)
 // (se_denseslam/src/kfusion/rendering_impl.hpp:34-74, bfusion/rendering_impl.hpp:35-68): writes the hit
 // (position, distance) or leaves it zero.  Shared by the raycast kernel and the volume renderer.
@@ -1682,7 +1795,16 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
     if (STATS) tk1 = __builtin_amdgcn_s_memtime();
   };
   // every thread of the workgroup goes through the set-up and the barrier; only rays inside the image enter the loop
+#if SE_FIRST_LEAF_LITE
+  bool redo = false;
+  RaySpan span = se_first_leaf_lite<SHALLOW>(m, a, org, dir, s_occ, redo, finish_staging, in_image);
+  if (__any(redo)) {   // (about one ray in 10^6, plus rays that miss the volume: the reference iterator with its stack)
+    const RaySpan full = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax, SeNoHook(), redo);
+    if (redo) span = {full.tcmin, full.tmax, span.trips + full.trips};
+  }
+#else
   const RaySpan span = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax, finish_staging, in_image);
+#endif
   if (in_image) {
     const float t_min = span.tcmin, tfar = span.tmax;
     if (STATS) tk2 = __builtin_amdgcn_s_memtime();

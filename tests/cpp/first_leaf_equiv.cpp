@@ -1,0 +1,144 @@
+// TEST INFRASTRUCTURE (never part of the product path): a CPU model of the stack-free first-leaf search of
+// k_raycast (supereight_amd/csrc/se_kernels.h, se_first_leaf_lite) checked ray by ray against the oracle's restatement
+// of se::ray_iterator (se_core/include/se/ray_iterator.hpp:53-226, oracle/se_oracle.cpp RayIterator).
+//
+// What the model claims.  The reference iterator carries, beside (pos, scale, t_min), a stack of (parent, t_max) per
+// scale and the value h.  For a ray that is *regular* at set-up (t_min < h: it enters the volume before it leaves it,
+// nothing is NaN) those carry no information:
+//   * parent: the node whose children are the cells of scale s is a function of pos (its heap code is the current
+//     code shifted right by three bits per level popped);
+//   * t_max = min(far / dim, root exit, tc_max of every ancestor cell on the path).  Every ancestor's tc_max is >= the
+//     tc_max of any cell inside it (t = pos * t_coef - t_bias is monotone in pos), and t_min only takes values tc_max of
+//     cells inside the current ancestors -- so `t_min <= t_max` is `t_min <= min(far / dim, root exit)` unless the ray
+//     descended from a cell whose own tc_max was already below t_min.  That can happen: the child slot is chosen by
+//     t_center = half * t_coef + t_corner, a different rounding of the same plane than the child's own t_corner, so a
+//     ray that passes within an ulp of a cell edge may be placed in a child it has, by t_corner, already left.  The
+//     model FLAGS exactly that event (descent with tc_max < t_min) and the kernel re-runs a flagged ray through the
+//     full iterator; so does a ray that is not regular at set-up;
+//   * h only decides whether a stack slot is (re)written, never what is read back (a slot that is read was written by
+//     the first descent below the same parent).
+// The test runs every pixel of a few frames through both and requires bit-identical t_min (leaf found or not) for all
+// rays that are neither flagged nor irregular, and reports how many are.
+#include "../../oracle/se_oracle.cpp"
+
+namespace fl {
+
+struct Result { float t_min; int found; int flagged; int irregular; int trips; };
+
+// the node whose children are the cells of `scale`, found from pos alone (what `code >> 3 * levels` is on the device)
+template <typename VT> static Node<VT>* node_at(const Octree<VT>& m, V3f pos, int scale, int om) {
+  Node<VT>* n = m.root_;
+  for (int s = CAST_STACK_DEPTH - 1; s > scale && n; --s) {
+    const int idx = ((f2i(pos.x) >> s) & 1) | (((f2i(pos.y) >> s) & 1) << 1) | (((f2i(pos.z) >> s) & 1) << 2);
+    n = n->child(idx ^ om);
+  }
+  return n;
+}
+
+template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f direction, float nearP, float farP) {
+  Result r = {0.f, 0, 0, 0, 0};
+  V3f pos = {1.f, 1.f, 1.f};
+  int scale = CAST_STACK_DEPTH - 1;
+  float scale_exp2 = 0.5f;
+  const int min_scale = CAST_STACK_DEPTH - (int)std::log2((double)(m.size_ / BLOCK_SIDE));
+  const float epsilon = exp2f(-(float)std::log2((double)m.size_));
+  V3f d;
+  d.x = fabsf(direction.x) < epsilon ? copysignf(epsilon, direction.x) : direction.x;
+  d.y = fabsf(direction.y) < epsilon ? copysignf(epsilon, direction.y) : direction.y;
+  d.z = fabsf(direction.z) < epsilon ? copysignf(epsilon, direction.z) : direction.z;
+  const V3f so = origin / m.dim_ + V3f{1.f, 1.f, 1.f};
+  const V3f tc = -1.f * V3f{1.f / fabsf(d.x), 1.f / fabsf(d.y), 1.f / fabsf(d.z)};
+  V3f tb = cwise(tc, so);
+  int om = 0;  // octant_mask ^ 7
+  if (d.x > 0.f) om ^= 1, tb.x = 3.f * tc.x - tb.x;
+  if (d.y > 0.f) om ^= 2, tb.y = 3.f * tc.y - tb.y;
+  if (d.z > 0.f) om ^= 4, tb.z = 3.f * tc.z - tb.z;
+  float t_min = fmaxf(fmaxf(2.f * tc.x - tb.x, 2.f * tc.y - tb.y), 2.f * tc.z - tb.z);
+  const float h0 = fminf(fminf(tc.x - tb.x, tc.y - tb.y), tc.z - tb.z);
+  t_min = fmaxf(t_min, nearP / m.dim_);
+  const float t_lim = fminf(h0, farP / m.dim_);   // t_max_init: the only t_max the model knows
+  if (!(t_min < h0)) { r.irregular = 1; r.t_min = t_min; return r; }
+  if (1.5f * tc.x - tb.x > t_min) pos.x = 1.5f;
+  if (1.5f * tc.y - tb.y > t_min) pos.y = 1.5f;
+  if (1.5f * tc.z - tb.z > t_min) pos.z = 1.5f;
+  Node<VT>* parent = m.root_;
+  while (scale < CAST_STACK_DEPTH) {
+    ++r.trips;
+    const V3f t_corner = cwise(pos, tc) - tb;
+    const float tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
+    const int idx = ((f2i(pos.x) >> scale) & 1) | (((f2i(pos.y) >> scale) & 1) << 1) | (((f2i(pos.z) >> scale) & 1) << 2);
+    if (!parent) { r.flagged = 2; break; }   // (would be a bug of the model: counted, never expected)
+    Node<VT>* child = parent->child(idx ^ om);
+    if (scale == min_scale && child) { r.found = 1; break; }
+    if (child && t_min <= t_lim) {
+      if (tc_max < t_min) { r.flagged = 1; break; }
+      const float half = scale_exp2 * 0.5f;
+      const V3f t_center = half * tc + t_corner;
+      parent = child;
+      --scale;
+      scale_exp2 = half;
+      if (t_center.x > t_min) pos.x += half;
+      if (t_center.y > t_min) pos.y += half;
+      if (t_center.z > t_min) pos.z += half;
+      continue;
+    }
+    // advance_ray without idx_: "leaves the parent" = a bit above `scale` changed
+    const V3f old = pos;
+    if (t_corner.x <= tc_max) pos.x -= scale_exp2;
+    if (t_corner.y <= tc_max) pos.y -= scale_exp2;
+    if (t_corner.z <= tc_max) pos.z -= scale_exp2;
+    t_min = tc_max;
+    const unsigned diff = (unsigned)(f2i(old.x) ^ f2i(pos.x)) | (unsigned)(f2i(old.y) ^ f2i(pos.y)) | (unsigned)(f2i(old.z) ^ f2i(pos.z));
+    if (diff > (1u << scale)) {
+      scale = 31 - __builtin_clz(diff);
+      scale_exp2 = i2f((scale - CAST_STACK_DEPTH + 127) << 23);
+      if (scale < CAST_STACK_DEPTH) {
+        const int keep = (int)(0xFFFFFFFFu << scale);
+        pos.x = i2f(f2i(pos.x) & keep); pos.y = i2f(f2i(pos.y) & keep); pos.z = i2f(f2i(pos.z) & keep);
+        parent = node_at(m, pos, scale, om);
+      }
+    }
+  }
+  r.t_min = t_min;
+  return r;
+}
+
+template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad) {
+  const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
+  const Octree<VT>& oct = p->oct;
+  int64_t rays = 0, irregular = 0, flagged = 0, mismatch = 0, found = 0, trips_ref = 0, trips_lite = 0, model_bug = 0;
+  int bad_x = -1, bad_y = -1;
+#pragma omp parallel for reduction(+ : rays, irregular, flagged, mismatch, found, trips_ref, trips_lite, model_bug)
+  for (int y = 0; y < p->H; ++y)
+    for (int x = 0; x < p->W; ++x) {
+      const V3f dir = normalized(mul3(top3(view), {(float)x, (float)y, 1.f}));
+      const V3f transl = {view.m[0][3], view.m[1][3], view.m[2][3]};
+      g_ray_iter = 0;
+      RayIterator<VT> ray(oct, transl, dir, nearPlane, farPlane);
+      const bool ref_found = ray.next() != nullptr;
+      const float ref_t = ray.t_min_;
+      trips_ref += g_ray_iter;
+      const Result r = lite(oct, transl, dir, nearPlane, farPlane);
+      ++rays;
+      trips_lite += r.trips;
+      if (r.irregular) { ++irregular; continue; }
+      if (r.flagged == 2) { ++model_bug; continue; }
+      if (r.flagged) { ++flagged; continue; }
+      found += r.found;
+      if (f2i(r.t_min) != f2i(ref_t) || (r.found != 0) != ref_found) {
+        ++mismatch;
+#pragma omp critical
+        { bad_x = x; bad_y = y; }
+      }
+    }
+  out[0] = rays; out[1] = irregular; out[2] = flagged; out[3] = mismatch; out[4] = found; out[5] = trips_ref; out[6] = trips_lite; out[7] = model_bug;
+  first_bad[0] = bad_x; first_bad[1] = bad_y;
+}
+
+}  // namespace fl
+
+extern "C" void fl_compare(void* pipe, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad) {
+  PipelineBase* b = (PipelineBase*)pipe;
+  if (auto* s = dynamic_cast<Pipeline<SDFv>*>(b)) fl::compare(s, pose_cm, k, out, first_bad);
+  else if (auto* o = dynamic_cast<Pipeline<OFv>*>(b)) fl::compare(o, pose_cm, k, out, first_bad);
+}
