@@ -1068,10 +1068,14 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
 #define SE_RAY(OF, ST, DN, SH) hipLaunchKernelGGL((k_raycast<OF, ST, DN, SH>), grid, block, smem, p->stream, m, a, p->vertex, p->normal)
     const bool shallow = !a.has_deep;   // every non-leaf occupancy level is in LDS (volumes <= 512^3): specialised traversal loop
+    // dense voxel planes of <= 4 GiB (512^3: 1 GiB): the lean march addresses them by 32-bit byte offsets from the scalar base
+    const size_t nb = (size_t)(m.size >> 3);
+    const bool o32 = m.dense && shallow && nb * nb * nb * (size_t)SE_BRICK_STRIDE * sizeof(float) <= ((size_t)4 << 30);
     const int variant = (sdf ? 0 : 4) | (p->stats ? 2 : 0) | (m.dense ? 1 : 0);
     switch (variant) {
       case 0: if (shallow) SE_RAY(false, false, false, true); else SE_RAY(false, false, false, false); break;
-      case 1: if (shallow) SE_RAY(false, false, true, true); else SE_RAY(false, false, true, false); break;
+      case 1: if (o32) hipLaunchKernelGGL((k_raycast<false, false, true, true, true>), grid, block, smem, p->stream, m, a, p->vertex, p->normal);
+              else if (shallow) SE_RAY(false, false, true, true); else SE_RAY(false, false, true, false); break;
       case 2: SE_RAY(false, true, false, false); break;
       case 3: SE_RAY(false, true, true, false); break;
       case 4: if (shallow) SE_RAY(true, false, false, true); else SE_RAY(true, false, false, false); break;

@@ -1544,9 +1544,202 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
 // (se_denseslam/src/kfusion/rendering_impl.hpp:34-74, bfusion/rendering_impl.hpp:35-68): writes the hit
 // (position, distance) or leaves it zero.  Shared by the raycast kernel and the volume renderer.
 struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
-template <bool OFUSION, bool STATS, bool DENSE>
+
+// ---- lean dense-grid march (r04) ---------------------------------------------------------------------------------
+// The raycast is bound by VALU issue slots, and by r03's counters two thirds of the march's instructions
+// were address arithmetic and range bookkeeping, not the reference's float operations.  For the dense grid:
+//  * float -> int by the hardware conversion (one instruction) instead of the compare-and-select restatement of x86's
+//    cvttss2si: the two agree for |f| < 2^31 and differ only for NaN (0 instead of INT_MIN) -- rays whose direction or
+//    origin is not finite never get here (k_raycast: their result is "no hit" whatever the volume holds, because the
+//    first interp returns NaN) and the host only selects these kernels for poses within 2^30 voxels of the volume;
+//  * "inside the volume" is one compare of the OR of the three integers (size is a power of two, a negative or saturated
+//    value has high bits set);
+//  * a voxel's index is the sum of one term per axis, (block part << 10) | local part, so a sample costs ~4 integer
+//    operations per axis and the 8 / 32 voxels of interp / grad one 3-input add each; maps of <= 4 GiB (O32: 512^3 dense)
+//    carry the terms as byte offsets and load through a 32-bit offset from the scalar base, the brick's y plane with an
+//    immediate offset from the same address (y = x + 512 floats, se_device.h);
+//  * the eight corners of sample 0 are fetched with the batch only while the march is inside the band (previous value
+//    < 1): in free or unobserved space they were ~100 instructions and 8 loads per batch that nobody used.  A sample
+//    that turns out to need them without having them pays one extra round trip (se_interp), results unchanged;
+//  * `(double)f_tt <= 0.1` is `f_tt < 0.1f` (0.1f is the smallest float above 0.1): no double-precision compare.
+#ifndef SE_MARCH_LEAN
+#define SE_MARCH_LEAN 1
+#endif
+__device__ __forceinline__ int se_cvt_hw(float f) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
+template <bool O32> struct SeDense;
+template <> struct SeDense<true> {     // byte-offset terms, 32 bit
+  typedef uint32_t idx_t;
+  static __device__ __forceinline__ idx_t tx(const DevMap&, uint32_t x) { return ((x >> 3) << 12) | ((x & 7u) << 2); }
+  static __device__ __forceinline__ idx_t ty(const DevMap& m, uint32_t y) { return ((y >> 3) << (12 + m.leaf_level)) | ((y & 7u) << 5); }
+  static __device__ __forceinline__ idx_t tz(const DevMap& m, uint32_t z) { return ((z >> 3) << (12 + 2 * m.leaf_level)) | ((z & 7u) << 8); }
+  static __device__ __forceinline__ idx_t sum(idx_t a, idx_t b, idx_t c) { return a + b + c; }
+  static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return *(const float*)((const char*)m.vx + (size_t)i); }
+  static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return *(const float*)((const char*)m.vx + (size_t)i + 2048); }
+};
+template <> struct SeDense<false> {    // (block sum, local sum) in 32 bit each, widened at the load
+  struct idx_t { uint32_t blk, loc; };
+  static __device__ __forceinline__ idx_t tx(const DevMap&, uint32_t x) { return {x >> 3, x & 7u}; }
+  static __device__ __forceinline__ idx_t ty(const DevMap& m, uint32_t y) { return {(y >> 3) << m.leaf_level, (y & 7u) << 3}; }
+  static __device__ __forceinline__ idx_t tz(const DevMap& m, uint32_t z) { return {(z >> 3) << (2 * m.leaf_level), (z & 7u) << 6}; }
+  static __device__ __forceinline__ idx_t sum(idx_t a, idx_t b, idx_t c) { return {a.blk + b.blk + c.blk, a.loc + b.loc + c.loc}; }
+  static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return m.vx[((size_t)i.blk << 10) | i.loc]; }
+  static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return m.vx[(((size_t)i.blk << 10) | i.loc) + 512]; }
+};
+template <bool O32> struct SeCell { float fx, fy, fz; typename SeDense<O32>::idx_t vi[8]; bool inside; };
+// the interpolation cell of a point given in voxel units (Octree::interp, octree.hpp:541-563): fractions and the eight
+// corner indices; inside = the whole cell lies in the volume (else the caller takes se_interp_generic)
+template <bool O32>
+__device__ __forceinline__ SeCell<O32> se_cell_lean(const DevMap& m, f3 pos) {
+  typedef SeDense<O32> A;
+  SeCell<O32> cell;
+  const float flx = floorf(pos.x), fly = floorf(pos.y), flz = floorf(pos.z);
+  const int bx = se_cvt_hw(flx), by = se_cvt_hw(fly), bz = se_cvt_hw(flz);
+  cell.fx = pos.x - flx; cell.fy = pos.y - fly; cell.fz = pos.z - flz;
+  const int lx = max(bx, 0), ly = max(by, 0), lz = max(bz, 0);
+  const int top = m.size - 1;
+  cell.inside = max(max(lx, ly), lz) < top;
+  const typename A::idx_t X[2] = {A::tx(m, lx), A::tx(m, lx + 1)}, Y[2] = {A::ty(m, ly), A::ty(m, ly + 1)}, Z[2] = {A::tz(m, lz), A::tz(m, lz + 1)};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cell.vi[k] = A::sum(X[k & 1], Y[(k >> 1) & 1], Z[k >> 2]);
+  return cell;
+}
+template <bool O32>
+__device__ __forceinline__ float se_interp_lean(const DevMap& m, const FieldConst fc, f3 pos, BlkCache& c) {
+  const SeCell<O32> cell = se_cell_lean<O32>(m, pos);
+  if (!cell.inside) return se_interp_generic<true>(m, fc, pos, c);   // a corner outside the volume
+  float p[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p[k] = SeDense<O32>::ldx(m, cell.vi[k]);
+  const float fx = cell.fx, fy = cell.fy, fz = cell.fz;
+  return (((p[0] * (1 - fx) + p[1] * fx) * (1 - fy) + (p[2] * (1 - fx) + p[3] * fx) * fy) * (1 - fz) +
+          ((p[4] * (1 - fx) + p[5] * fx) * (1 - fy) + (p[6] * (1 - fx) + p[7] * fx) * fy) * fz);
+}
+// Octree::grad on the dense grid (same terms and order as se_grad); falls back to the generic form when an index leaves the volume
+template <bool O32>
+__device__ __forceinline__ f3 se_grad_lean(const DevMap& m, const FieldConst fc, f3 pos, BlkCache& c) {
+  typedef SeDense<O32> A;
+  const float flx = floorf(pos.x), fly = floorf(pos.y), flz = floorf(pos.z);
+  const int bx = se_cvt_hw(flx), by = se_cvt_hw(fly), bz = se_cvt_hw(flz);
+  const int hi = m.size - 1;
+  if (!(bx <= hi && by <= hi && bz <= hi)) return se_grad_generic<true>(m, fc, pos, c);
+  const float fx = pos.x - flx, fy = pos.y - fly, fz = pos.z - flz;
+  const typename A::idx_t X[4] = {A::tx(m, max(bx - 1, 0)), A::tx(m, max(bx, 0)), A::tx(m, min(bx + 1, hi)), A::tx(m, min(bx + 2, hi))};
+  const typename A::idx_t Y[4] = {A::ty(m, max(by - 1, 0)), A::ty(m, max(by, 0)), A::ty(m, min(by + 1, hi)), A::ty(m, min(by + 2, hi))};
+  const typename A::idx_t Z[4] = {A::tz(m, max(bz - 1, 0)), A::tz(m, max(bz, 0)), A::tz(m, min(bz + 1, hi)), A::tz(m, min(bz + 2, hi))};
+  float V[4][4][4];
+#pragma unroll
+  for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+    for (int yi = 0; yi < 4; ++yi)
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const int central = (xi == 1 || xi == 2) + (yi == 1 || yi == 2) + (zi == 1 || zi == 2);
+        if (central < 2) continue;
+        V[zi][yi][xi] = A::ldx(m, A::sum(X[xi], Y[yi], Z[zi]));
+      }
+  f3 g;
+  g.x = (((V[1][1][2] - V[1][1][0]) * (1 - fx) + (V[1][1][3] - V[1][1][1]) * fx) * (1 - fy) +
+         ((V[1][2][2] - V[1][2][0]) * (1 - fx) + (V[1][2][3] - V[1][2][1]) * fx) * fy) * (1 - fz) +
+        (((V[2][1][2] - V[2][1][0]) * (1 - fx) + (V[2][1][3] - V[2][1][1]) * fx) * (1 - fy) +
+         ((V[2][2][2] - V[2][2][0]) * (1 - fx) + (V[2][2][3] - V[2][2][1]) * fx) * fy) * fz;
+  g.y = (((V[1][2][1] - V[1][0][1]) * (1 - fx) + (V[1][2][2] - V[1][0][2]) * fx) * (1 - fy) +
+         ((V[1][3][1] - V[1][1][1]) * (1 - fx) + (V[1][3][2] - V[1][1][2]) * fx) * fy) * (1 - fz) +
+        (((V[2][2][1] - V[2][0][1]) * (1 - fx) + (V[2][2][2] - V[2][0][2]) * fx) * (1 - fy) +
+         ((V[2][3][1] - V[2][1][1]) * (1 - fx) + (V[2][3][2] - V[2][1][2]) * fx) * fy) * fz;
+  g.z = (((V[2][1][1] - V[0][1][1]) * (1 - fx) + (V[2][1][2] - V[0][1][2]) * fx) * (1 - fy) +
+         ((V[2][2][1] - V[0][2][1]) * (1 - fx) + (V[2][2][2] - V[0][2][2]) * fx) * fy) * (1 - fz) +
+        (((V[3][1][1] - V[1][1][1]) * (1 - fx) + (V[3][1][2] - V[1][1][2]) * fx) * (1 - fy) +
+         ((V[3][2][1] - V[1][2][1]) * (1 - fx) + (V[3][2][2] - V[1][2][2]) * fx) * fy) * fz;
+  return g;
+}
+// one get(): voxel coordinates, inside-the-volume flag and index of the sample at q (metres)
+template <bool O32> struct SeSample { typename SeDense<O32>::idx_t vi; bool in; };
+template <bool O32>
+__device__ __forceinline__ SeSample<O32> se_sample_lean(const DevMap& m, const RayArgs& a, f3 q) {
+  typedef SeDense<O32> A;
+  const int ix = se_cvt_hw(a.inv_voxel * q.x), iy = se_cvt_hw(a.inv_voxel * q.y), iz = se_cvt_hw(a.inv_voxel * q.z);
+  SeSample<O32> s;
+  s.in = (uint32_t)(ix | iy | iz) < (uint32_t)m.size;
+  const uint32_t ux = s.in ? (uint32_t)ix : 0u, uy = s.in ? (uint32_t)iy : 0u, uz = s.in ? (uint32_t)iz : 0u;   // (outside: voxel 0, value replaced)
+  s.vi = A::sum(A::tx(m, ux), A::ty(m, uy), A::tz(m, uz));
+  return s;
+}
+// raycast(const Volume<SDF>&, ...) (se_denseslam/src/kfusion/rendering_impl.hpp:34-74) on the dense grid; same float
+// operations in the same order as se_cast_ray's generic form below (which stays the path of pooled bricks)
+template <bool STATS, bool O32>
+__device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
+                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  typedef SeDense<O32> A;
+  if (!(tnear < tfar)) return;
+  float t = tnear;
+  float stepsize = a.largestep;
+  f3 position = f3_add(org, f3_scale_r(dir, t));
+  float f_t = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, position), c);
+  if (STATS) ++rc.n_interp;
+  float f_tt = 0;
+  if (!(f_t > 0)) return;
+  float S = a.largestep;
+  bool done = false;
+  bool band = f_t < 1.f;   // the last value seen was inside the truncation band: the next sample probably wants its interpolated value
+  for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+    ++rc.n_batch;
+    const f3 q0 = position;
+    const f3 q1 = f3_add(q0, f3_scale(S, dir));
+    const SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
+    const float x0 = A::ldx(m, s0.vi), y0 = A::ldy(m, s0.vi), x1 = A::ldx(m, s1.vi), y1 = A::ldy(m, s1.vi);
+    SeCell<O32> cell0;
+    float cv0[8];
+    bool have0 = false;
+    if (band) {
+      cell0 = se_cell_lean<O32>(m, f3_scale(a.inv_voxel, q0));
+      have0 = cell0.inside;
+      if (have0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv0[k] = A::ldx(m, cell0.vi[k]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!(t < tfar)) { done = true; break; }
+      if (STATS) ++rc.n_get;
+      const bool ok = i ? s1.in : s0.in;
+      const float dx = ok ? (i ? x1 : x0) : fc.init_x, dy = ok ? (i ? y1 : y0) : fc.init_y;
+      if (dy == 0) {
+        stepsize = a.largestep;
+        position = f3_add(position, f3_scale(stepsize, dir));
+        band = false;
+      } else {
+        f_tt = dx;
+        if (f_tt < 0.1f && f_tt >= -0.5f) {   // (double)f_tt <= 0.1
+          if (i == 0 && have0) {
+            const float fx = cell0.fx, fy = cell0.fy, fz = cell0.fz;
+            f_tt = (((cv0[0] * (1 - fx) + cv0[1] * fx) * (1 - fy) + (cv0[2] * (1 - fx) + cv0[3] * fx) * fy) * (1 - fz) +
+                    ((cv0[4] * (1 - fx) + cv0[5] * fx) * (1 - fy) + (cv0[6] * (1 - fx) + cv0[7] * fx) * fy) * fz);
+          } else {
+            f_tt = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, position), c);
+          }
+          if (STATS) ++rc.n_interp;
+        }
+        if (f_tt < 0) { done = true; break; }
+        stepsize = fmaxf(f_tt * a.mu, a.step);
+        position = f3_add(position, f3_scale(stepsize, dir));
+        f_t = f_tt;
+        band = f_tt < 1.f;
+      }
+      t += stepsize;
+      if (stepsize != S) { S = stepsize; break; }
+    }
+  }
+  if (f_tt < 0) {
+    t = t + stepsize * f_tt / (f_t - f_tt);
+    const f3 r = f3_add(org, f3_scale_r(dir, t));
+    hx = r.x; hy = r.y; hz = r.z; hw = t;
+  }
+}
+template <bool OFUSION, bool STATS, bool DENSE, bool O32 = false>
 __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
                                             BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  if (SE_MARCH_LEAN && !OFUSION && DENSE) { se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
   unsigned long long& n_get = rc.n_get;
   unsigned long long& n_interp = rc.n_interp;
   {
@@ -1733,7 +1926,7 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 #else
 #define SE_RAY_OCC
 #endif
-template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW>
+template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW, bool O32 = false>   // O32: the voxel planes span <= 4 GiB (dense 512^3): 32-bit byte offsets
 __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
   // LDS: [occupancy words of levels 1..cache_levels][ray stack: parent codes][ray stack: t_max]
   extern __shared__ uint32_t smem[];
@@ -1812,7 +2005,7 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
     BlkCache c = {-1, -1, -1, 0u};
     if (t_min > 0.f && !(SE_DBG_PHASES(a) & 1)) {
       RayCounters rc = {0ull, 0ull, 0u};
-      se_cast_ray<OFUSION, STATS, DENSE>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+      se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
       if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
       my_cost = 5u * rc.n_batch;
 #ifdef SE_DIAG
@@ -1827,12 +2020,12 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
     float* v = vertex + 3 * (size_t)(px + py * a.W);
     float* n = normal + 3 * (size_t)(px + py * a.W);
     if (SE_DBG_PHASES(a) & 1) hw = t_min;
-    if ((double)hw > 0.0 && (SE_DBG_PHASES(a) & 3)) {
+    if (hw > 0.f && (SE_DBG_PHASES(a) & 3)) {
       v[0] = hx; v[1] = hy; v[2] = hw; n[0] = 0.f; n[1] = 0.f; n[2] = 0.f;
-    } else if ((double)hw > 0.0) {
+    } else if (hw > 0.f) {   // (hit.w() > 0.0)
       if (STATS) { ++n_hit; ++n_grad; }
       v[0] = hx; v[1] = hy; v[2] = hz;
-      const f3 g = se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
+      const f3 g = (SE_MARCH_LEAN && DENSE) ? se_grad_lean<O32>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c) : se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
       const f3 surfNorm = f3_scale(a.grad_scale, g);
       if (sqrtf(f3_sqnorm(surfNorm)) == 0) {
         n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;  // INVALID (commons.h:71)
