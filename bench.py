@@ -185,7 +185,8 @@ def cpu_baseline(args, n_timed: int):
             t1 += time.perf_counter() - t0
     o.close()
     single = n1 / t1
-    return {"value": fps, "unit": "frames/s", "cores": int(threads), "kind": "port",
+    return {"value": fps, "value_kind": "median repetition of the better thread count (r02 and earlier: the fastest repetition, kept as best_repetition_fps)",
+            "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"frames 4..{3 + n_timed} of the same stream after 4 executed warm-up frames "
                       f"({n_timed} timed frames, median of {len(reps)} repetitions, OpenMP {threads} threads, "
                       f"{'-march=native' if native else '-march=x86-64-v3'} build)",
@@ -560,6 +561,11 @@ def main():
                 rr["frames"] = [lo, hi - 1]
                 rr["kernels_us"] = {kk: round(v["avg_us"], 2) for kk, v in pk.items()}
                 result["roofline_replay"][name] = rr
+        # the fraction to quote is the longest window's (4 live samples move by 10 % with the window); the live figure stays `frac`
+        longest = result["roofline_replay"].get("sustained") or result["roofline_replay"].get("contract")
+        if longest:
+            result["roofline"]["frac_sustained"] = longest["frac"]
+            result["roofline"]["frac_sustained_window"] = f"frames {longest['frames'][0]}..{longest['frames'][1]}, every launch timed (untimed replay)"
 
     # ---- legs beside the contract line (every rank takes part)
     def timed_leg(make, ptrs, pcm, kk, warm_, K_):
@@ -607,6 +613,29 @@ def main():
                                             "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists"}}
         del dev4
 
+    if rank == 0 and world == 1:
+        # SURVEY 8(d)'s own bracketing (se_apps/src/benchmark.cpp:148-167: wall clock around integration() + raycasting()
+        # including the device sync, frame by frame): the SAME K frames as `value`, a fresh map, one se_hip_sync() per frame,
+        # nothing of frame f+1 issued before frame f has finished.  This is the figure a SLAM loop whose next pose depends
+        # on this frame's raycast gets; `value` is the pipelined rate of a caller that knows its poses in advance.
+        cp = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=local_rank)
+        _, cscratch = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else (0, None)
+        for f in range(warm):
+            cp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
+            cp.sync()
+        tc0 = time.perf_counter()
+        for f in range(warm, warm + K):
+            cp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
+            cp.sync()
+        tc1 = time.perf_counter()
+        cp.counts()
+        cp.close()
+        if cscratch is not None:
+            cscratch.close()
+        result["value_closed_loop"] = K / (tc1 - tc0)
+        result["ms_per_step_closed_loop"] = 1e3 * (tc1 - tc0) / K
+        result["value_note"] = ("value = K pipelined frames / wall time (poses known in advance: scan(f+1) runs beside raycast(f)); "
+                                "value_closed_loop = the same K frames with a device sync after every frame, SURVEY 8(d)'s bracketing")
     if rank == 0 and world == 1 and not args.no_modes:
         result["modes"] = extra_modes(args, field, depth_ptrs, poses, k, warm, min(args.mode_frames, F - warm), local_rank)
         if args.stream != "stress" and not args.raw:

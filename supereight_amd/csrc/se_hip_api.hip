@@ -135,6 +135,7 @@ struct se_hip_pipeline {
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
+  bool of_scan_tiled = true;  // OFusion allocation scan: the tiled two-pass kernel (SE_HIP_OF_SCAN_TILED=0: one thread per pixel, r03)
   float* depth_own = nullptr;       // width*height floats
   const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
   unsigned short* depth_mm = nullptr;
@@ -447,6 +448,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->row_end = (cfg->row_end > cfg->row_begin) ? cfg->row_end : cfg->height;
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_OF_SCAN_TILED")) p->of_scan_tiled = std::atoi(ev) != 0;   // A/B knob
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
 #ifdef SE_DIAG
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
@@ -790,8 +792,30 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
         else hipLaunchKernelGGL((k_alloc_scan_sdf<false, false>), sgrid, block, 0, s, ms, p->depth, a);
       }
     } else {
-      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
-      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
+      // the three stages' levels (fetch_octant stops at the leaves) and their offsets in the index pyramid
+      const int dep[3] = {a.depth_fine, a.depth_mid, a.depth_coarse};
+      bool tiled = p->of_scan_tiled;
+      for (int i = 0; i < 3; ++i) {
+        a.of_lvl[i] = std::min(dep[i], m.leaf_level);
+        if (a.of_lvl[i] < 1) tiled = false; else a.of_off[i] = m.off[a.of_lvl[i]];
+      }
+      // the tiled kernel takes "the octant is a block" as "stage 0": true for every volume the reference's step sizes produce
+      // (depths max, max - 4, max - 5 against leaves at max - 3); anything else goes through the one-thread-per-pixel kernel
+      tiled = tiled && dep[0] >= m.leaf_level && dep[1] < m.leaf_level && dep[2] < m.leaf_level && m.off[m.leaf_level] + ((size_t)1 << (3 * m.leaf_level)) < ((size_t)1 << 30);
+      if (tiled) {
+        const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);   // a wave = an 8x8 pixel tile
+        const dim3 sgrid((tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
+        if (m.dense) {
+          if (p->stats) hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<true, true>), sgrid, block, 0, s, ms, p->depth, a);
+          else hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<false, true>), sgrid, block, 0, s, ms, p->depth, a);
+        } else {
+          if (p->stats) hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<true, false>), sgrid, block, 0, s, ms, p->depth, a);
+          else hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<false, false>), sgrid, block, 0, s, ms, p->depth, a);
+        }
+      } else {
+        if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
+        else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
+      }
     }
   }
   if (ov) {
@@ -1079,7 +1103,8 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
       case 2: SE_RAY(false, true, false, false); break;
       case 3: SE_RAY(false, true, true, false); break;
       case 4: if (shallow) SE_RAY(true, false, false, true); else SE_RAY(true, false, false, false); break;
-      case 5: if (shallow) SE_RAY(true, false, true, true); else SE_RAY(true, false, true, false); break;
+      case 5: if (o32) hipLaunchKernelGGL((k_raycast<true, false, true, true, true>), grid, block, smem, p->stream, m, a, p->vertex, p->normal);
+              else if (shallow) SE_RAY(true, false, true, true); else SE_RAY(true, false, true, false); break;
       case 6: SE_RAY(true, true, false, false); break;
       case 7: SE_RAY(true, true, true, false); break;
     }

@@ -119,6 +119,8 @@ struct AllocArgs {
   int num_steps;    // SDF: ceil(band * inv_voxel)
   int W, H, row_begin, row_end;
   int depth_fine, depth_mid, depth_coarse;  // OFusion: step_to_depth() of the three step sizes
+  int of_lvl[3];            // min(depth, leaf level) of the three stages (fetch_octant stops at the leaves) ...
+  uint32_t of_off[3];       // ... and the offset of that level in the index pyramid (DevMap::off is never indexed dynamically on the device)
   int sharded;      // this replica scans only part of the image: report re-activated blocks to the peers
 };
 
@@ -315,6 +317,116 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, con
         step = f3_scale_r(direction, stepsize);
         voxelPos = f3_add(voxelPos, step);
       }
+    }
+  }
+  se_stat_add<STATS>(m, S_PROBES, probes);
+  se_stat_add<STATS>(m, S_NEWKEYS, newk);
+}
+
+// r04: the same scan with the SDF scan's structure (the r03 kernel above took 75 us at 512^3 / mu 0.008 -- one thread per pixel in
+// row-major order, one *dependent* index load per distinct octant, ~10 of them per ray).  A wave scans an 8x8 pixel tile; pass 1
+// walks the ray with the reference's float arithmetic and only records the distinct (stage, octant) pairs in LDS; pass 2 fetches
+// the entries of all of them in one round trip (dense bricks, leaf stage: the `active` byte first, the index only for blocks that
+// are not active yet -- which also drops the ~2 byte stores per ray onto a few thousand addresses).  `travelled`, and with it the
+// step size and tree depth of step i, is the same for every ray (only `dist` differs), so level, shift and pyramid offset of a step
+// are wave-uniform.  floor() is taken as an integer in one instruction and the six range tests as one test on the OR, as in
+// k_alloc_scan_sdf (a ray with a non-finite origin or direction is skipped: none of its steps passes the reference's tests).
+// A record = stage << 30 | index into tab[].
+#ifndef SE_OF_SCAN_SLOTS
+#define SE_OF_SCAN_SLOTS 8
+#endif
+template <bool STATS, bool DENSE>
+__device__ __forceinline__ void se_of_scan_flush(const DevMap& m, const AllocArgs& a, const uint32_t* s_rec, int nb, unsigned long long& newk) {
+  uint32_t rec[SE_OF_SCAN_SLOTS], val[SE_OF_SCAN_SLOTS];
+#pragma unroll
+  for (int k = 0; k < SE_OF_SCAN_SLOTS; ++k) rec[k] = s_rec[k * SE_WG_SCAN];
+#pragma unroll
+  for (int k = 0; k < SE_OF_SCAN_SLOTS; ++k) {
+    const uint32_t r = k < nb ? rec[k] : rec[0];
+    const uint32_t ti = r & 0x3FFFFFFFu;
+    val[k] = (DENSE && (r >> 30) == 0u) ? (uint32_t)m.bactive[ti - a.of_off[0]] : m.tab[ti];
+  }
+#pragma unroll
+  for (int k = 0; k < SE_OF_SCAN_SLOTS; ++k) {
+    if (k >= nb) continue;
+    const uint32_t stage = rec[k] >> 30, ti = rec[k] & 0x3FFFFFFFu;
+    const int lvl = stage == 0u ? a.of_lvl[0] : (stage == 1u ? a.of_lvl[1] : a.of_lvl[2]);
+    const uint32_t off = stage == 0u ? a.of_off[0] : (stage == 1u ? a.of_off[1] : a.of_off[2]);
+    const uint32_t lin = ti - off, mask = (1u << lvl) - 1u;
+    const int ox = (int)(lin & mask), oy = (int)((lin >> lvl) & mask), oz = (int)(lin >> (2 * lvl));
+    const bool leaf = stage == 0u;   // tree_depth >= leaves_depth: the octant is a block (the host selects this kernel only if that is stage 0 alone)
+    uint32_t e;
+    if (DENSE && stage == 0u) {
+      if (leaf && val[k]) continue;                  // exists and is active already
+      e = m.tab[ti];
+    } else {
+      e = val[k];
+    }
+    if (e == 0u) {
+      if (se_insert_octant(m, lvl, ox, oy, oz)) { se_append_key(m, lvl, ox, oy, oz); ++newk; }
+    } else if (leaf && e != SE_PENDING) {
+      se_mark_active(m, e - 1u, a.sharded != 0, ox, oy, oz);
+    }
+  }
+}
+template <bool STATS, bool DENSE>
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion_tiled(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+  __shared__ uint32_t s_rec_all[SE_OF_SCAN_SLOTS * SE_WG_SCAN];
+  uint32_t* s_rec = s_rec_all + threadIdx.x;
+  unsigned long long probes = 0, newk = 0;
+  int x, y;
+  bool in_image;
+  {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
+    const int tiles_x = (a.W + 7) >> 3;
+    x = (tile % tiles_x) * 8 + (lane & 7);
+    y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
+    in_image = x < a.W && y < a.row_end;
+  }
+  if (in_image) {
+    const float depth = depthmap[x + y * a.W];
+    if (!(depth == 0)) {
+      const f3 worldVertex = m34_mul_h(a.kpose, {(x + 0.5f) * depth, (y + 0.5f) * depth, depth});
+      const f3 camera = {a.cam[0], a.cam[1], a.cam[2]};
+      const f3 direction = f3_normalized(f3_sub(camera, worldVertex));
+      const f3 origin = f3_sub(worldVertex, f3_scale(a.band * 0.5f, direction));
+      const float dist = sqrtf(f3_sqnorm(f3_sub(camera, origin)));
+      const bool finite = fabsf(origin.x) < INFINITY && fabsf(origin.y) < INFINITY && fabsf(origin.z) < INFINITY &&
+                          fabsf(direction.x) < INFINITY && fabsf(direction.y) < INFINITY && fabsf(direction.z) < INFINITY;
+      const uint32_t hi_mask = ~(uint32_t)(m.size - 1);
+      const float hf_band = a.band, half = a.band * 0.5f;
+      float stepsize = a.voxel;
+      int stage = 0;                 // (tree_depth starts at max_depth: the leaf stage whenever depth_fine does)
+      int lvl = m.max_level < m.leaf_level ? m.max_level : m.leaf_level;
+      uint32_t off = a.of_off[0];
+      f3 voxelPos = origin;
+      uint32_t last = 0xFFFFFFFFu;
+      int nb = 0;
+      for (float travelled = 0.f; finite && travelled < dist; travelled += stepsize) {
+        const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
+        const int ix = se_cvt_flr(s.x), iy = se_cvt_flr(s.y), iz = se_cvt_flr(s.z);
+        if ((((uint32_t)ix | (uint32_t)iy | (uint32_t)iz) & hi_mask) == 0u) {
+          ++probes;
+          const int sh = m.max_level - lvl;
+          const uint32_t lin = ((((uint32_t)iz >> sh) << lvl | ((uint32_t)iy >> sh)) << lvl) | ((uint32_t)ix >> sh);
+          const uint32_t rec = ((uint32_t)stage << 30) | (off + lin);
+          if (rec != last) {
+            last = rec;
+            if (nb == SE_OF_SCAN_SLOTS) { se_of_scan_flush<STATS, DENSE>(m, a, s_rec, nb, newk); nb = 0; }
+            s_rec[nb * SE_WG_SCAN] = rec;
+            ++nb;
+          }
+        }
+        // compute_stepsize / step_to_depth (alloc_impl.hpp:37-51); depths evaluated on the host with the C library's log2f
+        if (travelled < hf_band) { stepsize = a.voxel; stage = 0; }
+        else if (travelled < hf_band + half) { stepsize = 10.f * a.voxel; stage = 1; }
+        else { stepsize = 30.f * a.voxel; stage = 2; }
+        lvl = stage == 0 ? a.of_lvl[0] : (stage == 1 ? a.of_lvl[1] : a.of_lvl[2]);
+        off = stage == 0 ? a.of_off[0] : (stage == 1 ? a.of_off[1] : a.of_off[2]);
+        voxelPos = f3_add(voxelPos, f3_scale_r(direction, stepsize));
+      }
+      if (nb) se_of_scan_flush<STATS, DENSE>(m, a, s_rec, nb, newk);
     }
   }
   se_stat_add<STATS>(m, S_PROBES, probes);
@@ -1736,10 +1848,62 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
     hx = r.x; hy = r.y; hz = r.z; hw = t;
   }
 }
+// raycast(const Volume<OFusion>&, ...) (se_denseslam/src/bfusion/rendering_impl.hpp:35-68) on the dense grid with the lean addressing
+// above; same float operations in the same order as the generic form in se_cast_ray
+template <bool STATS, bool O32>
+__device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
+                                                    BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  typedef SeDense<O32> A;
+  if (!(tnear < tfar)) return;
+  float t = tnear;
+  const float stepsize = a.step;
+  float f_t = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
+  if (STATS) ++rc.n_interp;
+  float f_tt = 0;
+  if (!(f_t <= 0.f)) return;
+  bool done = false;
+  for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+    ++rc.n_batch;
+    float tt[SE_SPEC_OF];
+    f3 q[SE_SPEC_OF];
+    SeSample<O32> sm[SE_SPEC_OF];
+    float qx[SE_SPEC_OF], qy[SE_SPEC_OF];
+    tt[0] = t;
+#pragma unroll
+    for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) { q[i] = f3_add(org, f3_scale_r(dir, tt[i])); sm[i] = se_sample_lean<O32>(m, a, q[i]); }
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) { qx[i] = A::ldx(m, sm[i].vi); qy[i] = A::ldy(m, sm[i].vi); }
+    bool stop = false;
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) {
+      if (stop) continue;
+      t = tt[i];
+      if (!(t < tfar)) { done = true; stop = true; continue; }
+      if (STATS) ++rc.n_get;
+      const float dx = sm[i].in ? qx[i] : fc.init_x, dy = sm[i].in ? qy[i] : fc.init_y;
+      if (dx > -100.f && dy > 0.f) {
+        f_tt = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
+        if (STATS) ++rc.n_interp;
+      }
+      if (f_tt > 0.f) { done = true; stop = true; continue; }
+      f_t = f_tt;
+    }
+    if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
+  }
+  if (f_tt > 0.f) {
+    t = t - stepsize * (f_tt - 0.f) / (f_tt - f_t);
+    const f3 r = f3_add(org, f3_scale_r(dir, t));
+    hx = r.x; hy = r.y; hz = r.z; hw = t;
+  }
+}
+
 template <bool OFUSION, bool STATS, bool DENSE, bool O32 = false>
 __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
                                             BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
   if (SE_MARCH_LEAN && !OFUSION && DENSE) { se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
+  if (SE_MARCH_LEAN && OFUSION && DENSE) { se_cast_ray_of_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
   unsigned long long& n_get = rc.n_get;
   unsigned long long& n_interp = rc.n_interp;
   {
