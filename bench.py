@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=20, help="timed frames of the CPU baseline sample")
     ap.add_argument("--cpu-reps", type=int, default=4, help="repetitions of the CPU baseline sample (the fastest is reported, all are listed)")
     ap.add_argument("--sustain", type=int, default=200, help="N = 1: after the K contract steps keep going until this many frames have been timed in total (0 = off)")
-    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU clock ramp-up before the warm-up frames (see prewarm())")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU warm-up on a scratch map before the warm-up frames (see prewarm())")
     ap.add_argument("--shard-sweep", action="store_true", help="N > 1: owner-computes integration + brick all-gather instead of the replicated sweep (SURVEY 8e option 4; DESIGN.md section 7: measured slower, off by default)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra N = 1 legs (closed loop, tracking on, pooled bricks)")
     ap.add_argument("--mode-frames", type=int, default=60, help="timed frames of each extra leg")
@@ -197,12 +197,23 @@ def cpu_baseline(args, n_timed: int):
             "single_thread": {"value": single, "unit": "frames/s", "sample": f"frames 4..{3 + n1}, 1 OpenMP thread"}}
 
 
+def freeze_gc():
+    """The import-time heap (torch + numpy: ~10^6 objects) moved out of the cyclic collector's sight.  Without this, a full
+    collection lands a few hundred frame calls into the first loop of the process -- the allocation count of the ctypes calls
+    triggers it -- and holds the interpreter for 35-60 ms, 400-700 frames' worth (profiles/r04f_stall_attribution.md).  It is
+    interpreter housekeeping of this harness, not part of the measured path (a C++ caller has no collector); nothing is
+    disabled: young generations are still collected."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def prewarm(args, field, depth_ptrs, poses, k, device, ms: float = 90.0):
     """Untimed: keeps the GPU busy with the same kernels on a scratch map for `ms` milliseconds right before a timed
-    region (the pipeline to be timed already exists by then).  An MI355X that has been idle sits in a low-power state; measured on the bench box (tools/long_run.py), the first
-    ~20 ms of sustained load end in ONE stall of 35-40 ms while the clocks come up (frames run 78-81 us before it and
-    75-76 us ever after, 3000 frames checked).  A 1.6 ms timed region either dodges it or, 200 frames long, eats it whole;
-    with the ramp behind us the K timed steps measure the steady state."""
+    region (the pipeline to be timed already exists by then): clocks, caches and code paths warm, so that the K timed steps
+    measure the steady state (frames run 78-81 us in the first ~20 ms of load after idle, 75-76 us ever after, tools/long_run.py).
+    r02-r03 also credited this with hiding "the one 35-40 ms clock-ramp stall"; that stall is CPython's garbage collector
+    (profiles/r04f_stall_attribution.md) and is dealt with where it belongs: freeze_gc() below."""
     from supereight_amd.pipeline import DenseSLAMPipeline
     p = DenseSLAMPipeline((args.width, args.height), args.res, args.dim, field_type=field, device=device)
     n = min(len(depth_ptrs), 24)
@@ -408,6 +419,7 @@ def main():
         if world > 1:
             dist.barrier()
 
+    freeze_gc()
     for f in range(warm):
         sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
     torch.cuda.synchronize()
@@ -464,7 +476,9 @@ def main():
                                    f"GT poses, frames {warm}..{warm + K - 1} timed",
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists" + (", sweep sharded by block owner + RCCL all-gather of the updated bricks" if sp.shard_sweep else ""),
                        "blocks_allocated": nblocks, "nodes_allocated": nnodes,
-                       "prewarm": f"{prewarm_frames} untimed frames on a scratch map before the W warm-up frames (GPU clock ramp, see bench.py prewarm())"},
+                       "prewarm": f"{prewarm_frames} untimed frames on a scratch map before the W warm-up frames (clocks / caches warm, see bench.py prewarm()); "
+                                  "gc.collect() + gc.freeze() before the warm-up frames (the interpreter's full collection over the import-time heap otherwise "
+                                  "lands inside the first loop: profiles/r04f_stall_attribution.md)"},
         }
         if sustained:
             result["sustained"] = sustained

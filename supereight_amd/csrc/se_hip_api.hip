@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -71,12 +72,18 @@ inline void cpu_relax() {
 #endif
 }
 // Polls `done()` for at most `limit_us` of wall-clock time (checked every 256 polls); false = gave up.
+// A successful poll is followed by an acquire fence: what the device wrote before the word the caller polls (the ICP record behind
+// its sequence number) must not be read by loads hoisted above the poll (aarch64 hosts, and the C++ memory model).
 template <typename F> bool spin_until(F done, long long limit_us) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned n = 1;; ++n) {
-    if (done()) return true;
+    if (done()) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
     cpu_relax();
-    if ((n & 255u) == 0u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > limit_us) return done();
+    if ((n & 255u) == 0u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > limit_us) {
+      const bool ok = done();
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return ok;
+    }
   }
 }
 
@@ -135,7 +142,8 @@ struct se_hip_pipeline {
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
-  bool of_scan_tiled = true;  // OFusion allocation scan: the tiled two-pass kernel (SE_HIP_OF_SCAN_TILED=0: one thread per pixel, r03)
+  bool of_scan_tiled = false; // OFusion allocation scan: SE_HIP_OF_SCAN_TILED=1 selects the tiled two-pass kernel (r04: bit-exact, 29.8 us against 18.8 us
+                              // for the one-thread-per-pixel kernel beside the same raycast, profiles/r04d_of_scan_ab.md -- off)
   float* depth_own = nullptr;       // width*height floats
   const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
   unsigned short* depth_mm = nullptr;

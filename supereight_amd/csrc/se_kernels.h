@@ -323,8 +323,12 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, con
   se_stat_add<STATS>(m, S_NEWKEYS, newk);
 }
 
-// r04: the same scan with the SDF scan's structure (the r03 kernel above took 75 us at 512^3 / mu 0.008 -- one thread per pixel in
-// row-major order, one *dependent* index load per distinct octant, ~10 of them per ray).  A wave scans an 8x8 pixel tile; pass 1
+// r04, built on VERDICT r03's request, measured, OFF by default (SE_HIP_OF_SCAN_TILED=1): the same scan with the SDF scan's structure.
+// Result (profiles/r04d_of_scan_ab.md, kernel trace + SQ counters, same bench, same box): 29.8 us / 7.3 M VALU / 481 k load instructions per
+// launch against 18.8 us / 5.0 M / 98 k for the kernel above -- whose 74.5 us in r03's trace were not its own: it ran beside a raycast that
+// held 5 x 88 VGPRs per SIMD and left it one wave slot; beside the r04 raycast (68 VGPRs) it gets four.  A ray has only ~10 distinct octants,
+// most consecutive probes repeat the previous one (no load at all in the kernel above), and the record / flush machinery costs more than the
+// round trips it batches.  A wave scans an 8x8 pixel tile; pass 1
 // walks the ray with the reference's float arithmetic and only records the distinct (stage, octant) pairs in LDS; pass 2 fetches
 // the entries of all of them in one round trip (dense bricks, leaf stage: the `active` byte first, the index only for blocks that
 // are not active yet -- which also drops the ~2 byte stores per ray onto a few thousand addresses).  `travelled`, and with it the

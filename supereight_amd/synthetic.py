@@ -230,9 +230,13 @@ class StressStream:
     """Same interface as SyntheticStream (``depth(f)`` in frame order, ``pose(f)``, ``k``); ICL-NUIM intrinsics with
     negative fy by default (BASELINE.json configs[0] / [2])."""
 
-    def __init__(self, width: int, height: int, dim: float, holes: bool = True, noise: bool = True, negative_fy: bool = True):
+    def __init__(self, width: int, height: int, dim: float, holes: bool = True, noise: bool = True, negative_fy: bool = True, time_scale: float = 1.0, start: float = 0.0):
         self.width, self.height, self.dim = width, height, float(dim)
         self.negative_fy = negative_fy
+        # time_scale < 1 samples the same camera path more densely (0.25: ~3 mm and 0.5 deg per frame, what a 30 Hz hand-held
+        # sensor delivers -- the regime in which the reference's ICP tracks; at 1.0 it rejects every frame, tests/test_gpu_tracking.py)
+        self.time_scale = float(time_scale)
+        self.start = float(start)     # path position of frame 0 (in frames of the unscaled path)
         self.k = intrinsics(width, negative_fy)
         self._holes = HoleStream() if holes else None
         self._noise = NoiseStream() if noise else None
@@ -242,7 +246,7 @@ class StressStream:
         if frame != self._next:
             raise ValueError("StressStream frames must be requested in order")
         self._next += 1
-        mm = render_stress_depth(frame, self.width, self.height, self.dim, self.negative_fy) * 1000.0
+        mm = render_stress_depth(self._time(frame), self.width, self.height, self.dim, self.negative_fy) * 1000.0
         if self._noise is not None:
             mm = mm + NOISE_SIGMA_MM * self._noise.normal(self.width * self.height).reshape(self.height, self.width)
         mm = np.clip(np.floor(mm), 0, 65535).astype(np.uint16)
@@ -253,7 +257,10 @@ class StressStream:
         return np.ascontiguousarray(d, dtype=np.float32)
 
     def pose(self, frame: int) -> np.ndarray:
-        return stress_pose(frame, self.dim)
+        return stress_pose(self._time(frame), self.dim)
+
+    def _time(self, frame: int):
+        return frame if (self.time_scale == 1.0 and self.start == 0.0) else self.start + frame * self.time_scale
 
 
 def stress_surface_distance(points: np.ndarray, dim: float) -> np.ndarray:

@@ -50,6 +50,8 @@ def child(cfg, n):
     if cfg.startswith("pooled"):
         kw["max_blocks"] = {512: 1 << 16, 1024: 1 << 19}.get(N, 1 << 21)
     out = {"cfg": cfg, "lib": os.environ.get("SE_HIP_LIB", "default").split("/")[-1]}
+    import gc
+    gc.collect(); gc.freeze()   # (profiles/r04f_stall_attribution.md)
     warm = 10
     # clock ramp: keep the GPU busy ~150 ms on a throw-away map
     p = DenseSLAMPipeline((W, H), N, 4.8, field_type=fld, **kw)

@@ -14,6 +14,8 @@ from supereight_amd.pipeline import DenseSLAMPipeline, SDF  # noqa: E402
 from supereight_amd.synthetic import StressStream, to_colmajor  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
+import gc  # noqa: E402
+gc.collect(); gc.freeze()   # the interpreter's full collection over the import-time heap otherwise lands in window 3 (r03: 2.6 k frames/s there; profiles/r04f_stall_attribution.md)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (320, 240)
 PATH = 360
