@@ -130,7 +130,8 @@ struct se_hip_pipeline {
   std::vector<float*> pyr_depth, pyr_vertex, pyr_normal;  // level 0 depth aliases the current depth image
   TrackData* track = nullptr;
   float* reduce_partial = nullptr;   // 8 x SE_TRACK_SEGMENTS x 32 partial sums of the running ICP iteration
-  IcpState* icp = nullptr;           // device: what one ICP iteration hands to the next
+  IcpState* icp = nullptr;           // device: what one ICP iteration hands to the next (two copies: launch j reads [j & 1], writes [(j + 1) & 1])
+  IcpState* icp_final = nullptr;     // the copy k_icp_finish of the last se_hip_track wrote
   IcpHostRecord* icp_host = nullptr; // pinned: the one record the host reads per tracked frame
   unsigned reduce_seq = 0;
   int track_iterations = 0;
@@ -1202,8 +1203,8 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   if (!p->track) {
     HIP_TRY(hipMalloc((void**)&p->track, (size_t)W * H * sizeof(TrackData)));
     HIP_TRY(hipMemsetAsync(p->track, 0, (size_t)W * H * sizeof(TrackData), s));
-    HIP_TRY(hipMalloc((void**)&p->reduce_partial, 8 * SE_TRACK_SEGMENTS * 32 * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&p->icp, sizeof(IcpState)));
+    HIP_TRY(hipMalloc((void**)&p->reduce_partial, 2 * 8 * SE_TRACK_SEGMENTS * 32 * sizeof(float)));   // the iterations' partial rows alternate
+    HIP_TRY(hipMalloc((void**)&p->icp, 2 * sizeof(IcpState)));                                       // ... and so does the state (k_icp_iter)
     HIP_TRY(hipHostMalloc((void**)&p->icp_host, sizeof(IcpHostRecord)));
     std::memset(p->icp_host, 0, sizeof(IcpHostRecord));
   }
@@ -1227,19 +1228,24 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     const float* src = i == 1 ? d0 : p->pyr_depth[i - 1];
     hipLaunchKernelGGL(k_half_sample, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_depth[i], w, h, src, W >> (i - 1), 0.1f * 3, 1);   // e_delta * 3
   }
-  for (int i = 0; i < n_levels; ++i) {
-    const int w = W >> i, h = H >> i;
-    const float kk[4] = {k[0] / float(1 << i), k[1] / float(1 << i), k[2] / float(1 << i), k[3] / float(1 << i)};
-    const M4 invK = inverse_camera_matrix(kk);
-    InvK ik;
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) ik.m[r * 4 + c] = invK.m[r][c];
-    const float* dsrc = i == 0 ? d0 : p->pyr_depth[i];
-    hipLaunchKernelGGL(k_depth2vertex, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_vertex[i], dsrc, w, h, ik);
-    hipLaunchKernelGGL(k_vertex2normal, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_normal[i], p->pyr_vertex[i], w, h, k[1] < 0 ? 1 : 0);
+  {
+    // depth2vertex / vertex2normal of every level: one launch each (grid.z = level; the blocks beyond a coarser level's size return at once)
+    PyrLevels L{};
+    for (int i = 0; i < n_levels; ++i) {
+      const float kk[4] = {k[0] / float(1 << i), k[1] / float(1 << i), k[2] / float(1 << i), k[3] / float(1 << i)};
+      const M4 invK = inverse_camera_matrix(kk);
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) L.K[i].m[r * 4 + c] = invK.m[r][c];
+      L.w[i] = W >> i; L.h[i] = H >> i;
+      L.depth[i] = i == 0 ? d0 : p->pyr_depth[i];
+      L.vertex[i] = p->pyr_vertex[i]; L.normal[i] = p->pyr_normal[i];
+    }
+    hipLaunchKernelGGL(k_depth2vertex_levels, dim3((W + 255) / 256, H, n_levels), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(k_vertex2normal_levels, dim3((W + 255) / 256, H, n_levels), dim3(256), 0, s, L, k[1] < 0 ? 1 : 0);
   }
-  // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, each
-  // two launches (k_icp_track: trackKernel + reduceKernel's partial sums; k_icp_update: final sums + updatePoseKernel); the pose, the convergence flags and the sums
-  // travel from launch to launch in device memory, and the host reads one pinned record when k_icp_finish has run.
+  // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, ONE launch each
+  // (k_icp_iter: the previous iteration's final sums + updatePoseKernel as a prologue, then trackKernel + reduceKernel's partial sums); the
+  // pose, the convergence flags and the sums travel from launch to launch in device memory (double-buffered), and the host reads one
+  // pinned record when k_icp_finish has run.
   const M4 pose0 = from_colmajor(pose_cm);
   const M4 projectReference = mul(camera_matrix(k), rigid_inverse(from_colmajor(p->raycast_pose)));
   TrackArgs a{};
@@ -1249,24 +1255,27 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   a.icp_threshold = icp_threshold;
   Pose16 P0;
   for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) P0.m[r * 4 + c] = pose0.m[r][c];
-  hipLaunchKernelGGL(k_icp_begin, dim3(1), dim3(64), 0, s, p->icp, P0);
+  const size_t part_words = (size_t)8 * SE_TRACK_SEGMENTS * 32;
+  int j = 0, prev_level = -1;
   for (int level = n_levels - 1; level >= 0; --level) {
     a.inW = W / (1 << level); a.inH = H / (1 << level);
     a.level = level;
-    for (int i = 0; i < pyramid[level]; ++i) {
-      hipLaunchKernelGGL(k_icp_track, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->icp, p->pyr_vertex[level], p->pyr_normal[level],
-                         p->vertex, p->normal, p->reduce_partial, a);
-      hipLaunchKernelGGL(k_icp_update, dim3(1), dim3(256), 0, s, p->icp, p->reduce_partial, a);
+    for (int i = 0; i < pyramid[level]; ++i, ++j) {
+      hipLaunchKernelGGL(k_icp_iter, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->icp + (j & 1), p->icp + ((j + 1) & 1), p->pyr_vertex[level],
+                         p->pyr_normal[level], p->vertex, p->normal, p->reduce_partial + ((j + 1) & 1) * part_words, p->reduce_partial + (j & 1) * part_words, a, prev_level, P0);
+      prev_level = level;
     }
   }
-  for (int level = 0; level < n_levels; ++level) {     // tracking_result_: the finest level that ran any iteration (k_icp_rows)
+  const unsigned seq = ++p->reduce_seq;
+  hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(SE_TRACK_LANES), 0, s, p->icp + (j & 1), p->icp + ((j + 1) & 1), p->reduce_partial + ((j + 1) & 1) * part_words,
+                     p->icp_host, W, H, seq, icp_threshold, prev_level, P0);
+  p->icp_final = p->icp + ((j + 1) & 1);
+  for (int level = 0; level < n_levels; ++level) {     // tracking_result_: the finest level that ran any iteration (k_icp_rows), with the pose its last iteration used
     if (pyramid[level] <= 0) continue;
     a.inW = W / (1 << level); a.inH = H / (1 << level); a.level = level;
-    hipLaunchKernelGGL(k_icp_rows, dim3((a.inW + 255) / 256, a.inH), dim3(256), 0, s, p->icp, p->track, p->pyr_vertex[level], p->pyr_normal[level], p->vertex, p->normal, a);
+    hipLaunchKernelGGL(k_icp_rows, dim3((a.inW + 255) / 256, a.inH), dim3(256), 0, s, p->icp_final, p->track, p->pyr_vertex[level], p->pyr_normal[level], p->vertex, p->normal, a);
     break;
   }
-  const unsigned seq = ++p->reduce_seq;
-  hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(64), 0, s, p->icp, p->icp_host, W, H, seq);
   HIP_TRY(hipGetLastError());
   // the one host wait of the frame: the record lands in pinned memory (bounded spin, then a stream synchronisation)
   volatile unsigned* seq_word = &p->icp_host->seq;

@@ -1,12 +1,13 @@
 // the consumer side of the raycast -- image pyramid + ICP tracking
 // (se_denseslam/src/preprocessing.cpp, tracking.cpp) on the device, so that vertex_ / normal_ never
-// leave HBM.  Same arithmetic contract as the hot path (se_device.h).  Since r03 the whole ICP loop is device-resident:
-// two launches per iteration (track + reduce; final sums + 6x6 solve + SE3 exponential + pose update + convergence test)
-// with the state in device memory, one host read per frame.
+// leave HBM.  Same arithmetic contract as the hot path (se_device.h).  Since r03 the whole ICP loop is device-resident, since r04
+// with ONE launch per iteration (k_icp_iter: the previous iteration's final sums + 6x6 solve + SE3 exponential + pose update +
+// convergence test as a redundant prologue of every workgroup, then track + reduce), the state in device memory, one host read per frame.
 #pragma once
 #include "se_device.h"
 
-#define SE_TRACK_SEGMENTS 128  // summation order of the reduction, see k_icp_track (r03: 16 -> 128: ~1 pixel per lane at 640x480, the pixel phase is one round of loads)
+#define SE_TRACK_SEGMENTS 32   // summation order of the reduction, see k_icp_iter (r02: 16, r03: 128, r04: 32 -- 256 workgroups, each of which repeats the previous
+                               // iteration's final sums and pose update in its prologue: 32 KB of partials per workgroup instead of 128 KB)
 #define SE_TRACK_LANES 256
 
 struct TrackData { int result; float error; float J[6]; };   // se_denseslam/include/se/commons.h:249-253
@@ -69,6 +70,22 @@ __global__ void k_depth2vertex(float* __restrict__ vertex, const float* __restri
   } else { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
 }
 
+// all pyramid levels in one launch (blockIdx.z = level): the per-level launches were ~2 us of kernel and ~4 us of launch boundary each
+struct PyrLevels { float* vertex[8]; float* normal[8]; const float* depth[8]; int w[8], h[8]; InvK K[8]; };
+__global__ void k_depth2vertex_levels(PyrLevels L) {
+  const int l = blockIdx.z, W = L.w[l], H = L.h[l];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W || y >= H) return;
+  float* v = L.vertex[l] + 3 * (size_t)(x + y * W);
+  const float d = L.depth[l][x + y * W];
+  const InvK& K = L.K[l];
+  if (d > 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      v[i] = (((d * K.m[i * 4 + 0]) * (float)x + (d * K.m[i * 4 + 1]) * (float)y) + (d * K.m[i * 4 + 2]) * 1.f) + (d * K.m[i * 4 + 3]) * 0.f;
+  } else { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
+}
+
 __device__ __forceinline__ f3 ld3(const float* p, int i) { return {p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]}; }
 __device__ __forceinline__ f3 f3_cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ float f3_dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
@@ -78,6 +95,24 @@ __global__ void k_vertex2normal(float* __restrict__ out, const float* __restrict
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= width || y >= height) return;
   float* o = out + 3 * (size_t)(x + y * width);
+  const f3 center = ld3(in, x + width * y);
+  if (center.z == 0.f) { o[0] = -2.f; return; }
+  const int plx = max(x - 1, 0), prx = min(x + 1, width - 1);
+  int puy, pdy;
+  if (negy) { puy = max(y - 1, 0); pdy = min(y + 1, height - 1); }
+  else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
+  const f3 left = ld3(in, plx + width * y), right = ld3(in, prx + width * y), up = ld3(in, x + width * puy), down = ld3(in, x + width * pdy);
+  if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
+  const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
+  o[0] = n.x; o[1] = n.y; o[2] = n.z;
+}
+
+__global__ void k_vertex2normal_levels(PyrLevels L, int negy) {
+  const int l = blockIdx.z, width = L.w[l], height = L.h[l];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  const float* in = L.vertex[l];
+  float* o = L.normal[l] + 3 * (size_t)(x + y * width);
   const f3 center = ld3(in, x + width * y);
   if (center.z == 0.f) { o[0] = -2.f; return; }
   const int plx = max(x - 1, 0), prx = min(x + 1, width - 1);
@@ -253,51 +288,171 @@ __device__ inline void se_se3_exp(const float a[6], float T[16]) {
 }
 
 struct Pose16 { float m[16]; };   // row-major 4x4
-__global__ void k_icp_begin(IcpState* s, Pose16 pose) {
-  const int i = threadIdx.x;
-  if (i < 16) { s->pose[i] = pose.m[i]; s->old_pose[i] = pose.m[i]; s->last_pose[i] = pose.m[i]; }
-  if (i < 32) s->reduce0[i] = 0.f;
-  if (i < 8) s->stop[i] = 0;
-  if (i == 0) { s->iterations = 0; s->tracked = 0; }
-}
-
-// One ICP iteration = two launches, no host in between.
-//  k_icp_track  = trackKernel + the first two stages of reduceKernel (tracking.cpp:62-302).  grid = (SE_TRACK_SEGMENTS, 8).  The
-//    reference leaves the summation order of the reduction to OpenMP; here (and in the oracle) it is fixed: strip b = rows
-//    y = b (mod 8) as in the reference, split into SE_TRACK_SEGMENTS contiguous segments, one workgroup each; lane t computes the
-//    TrackData of pixels t, t+256, ... of its segment and accumulates them in that order; the 256 partials are combined by a
-//    binary tree.
-//  k_icp_update = the rest of reduceKernel + updatePoseKernel (tracking.cpp:205-224, 304-318): per strip the segments are added in
-//    order (8 x 32 lanes in parallel), then the strips in order; one lane solves the 6x6 system, applies exp(x) to the pose and
-//    evaluates the convergence test, all in the oracle's order; pose, flags and sums stay in device memory for the next launch.
-// (A single launch per iteration with a last-workgroup ticket was built first and was slower: 25 us per iteration against 16 for
-//  r02's three launches + host round trip -- 256 workgroups each paid an agent-scope fence and an atomic on one word, and ~5 pixels
-//  per lane made the pixel phase five dependent rounds of gathers.)
-__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __restrict__ s, const float* __restrict__ inVertex,
-                                                               const float* __restrict__ inNormal, const float* __restrict__ refVertex,
-                                                               const float* __restrict__ refNormal, float* __restrict__ partial, TrackArgs a) {
-  __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
-  if (s->stop[a.level]) return;                 // the level has converged: the reference's `break` (set by an earlier launch only)
-  const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
-  float T[12];
+// One ICP iteration = ONE launch, no host in between, no atomics (r04; r03: two launches, k_icp_track + k_icp_update, ~15 us per
+// iteration of which 4.7 us were the single-workgroup update kernel and 3.6 us the two kernel boundaries).
+//  k_icp_iter(j) = [prologue: the rest of iteration j-1] + [trackKernel and the first two stages of reduceKernel of iteration j].
+//   Prologue (tracking.cpp:205-224, 304-318), executed by EVERY workgroup redundantly -- the result is the same everywhere, so no
+//   workgroup has to wait for another and only workgroup (0, 0) stores it: per strip the SE_TRACK_SEGMENTS partial rows of iteration
+//   j-1 are added in order (8 x 32 lanes in parallel), then the strips in order; one lane solves the 6x6 system, applies exp(x) to
+//   the pose and evaluates the convergence test, all in the oracle's order.  State is double-buffered (launch j reads state[j & 1]
+//   and writes state[(j + 1) & 1]) so that workgroup (0, 0) never overwrites what a later-starting workgroup still has to read; the
+//   partial rows alternate likewise.
+//   Pixel phase (tracking.cpp:62-302), grid = (SE_TRACK_SEGMENTS, 8).  The reference leaves the summation order of the reduction to
+//   OpenMP; here (and in the oracle) it is fixed: strip b = rows y = b (mod 8) as in the reference, split into SE_TRACK_SEGMENTS
+//   contiguous segments, one workgroup each; lane t computes the TrackData of pixels t, t+256, ... of its segment and accumulates
+//   them in that order; the 256 partials are combined by a binary tree.  A lane has ~5 pixels on the 640x480 level: their loads are
+//   issued together (inputs, then the gathers at the projected positions), the rows are accumulated afterwards, in order.
+//  k_icp_finish = the prologue once more (the last iteration's sums and update) + checkPoseKernel + the host record.
+// (r03's first single-launch attempt used a last-workgroup ticket and was slower than r02: every workgroup paid an agent-scope fence
+//  and an atomic on one word.)
+struct IcpShared { float strip[8][32]; float pose[16]; int conv; };
+// the rest of iteration `prev`: final sums -> sh.strip[0], pose update -> sh.pose, convergence -> sh.conv; P = the pose it tracked with
+__device__ __forceinline__ void se_icp_finalize(IcpShared& sh, const float* __restrict__ partial, const float* P, float icp_threshold) {
+  const int t = threadIdx.x, bb = t >> 5, i = t & 31;
+  if (t < 256) {
+    float total = 0.f;
+    for (int gg = 0; gg < SE_TRACK_SEGMENTS; ++gg) total += partial[(bb * SE_TRACK_SEGMENTS + gg) * 32 + i];
+    sh.strip[bb][i] = total;
+  }
+  __syncthreads();
+  if (t < 32) {
+    float row0 = sh.strip[0][t];
+    for (int b2 = 1; b2 < 8; ++b2) row0 += sh.strip[b2][t];
+    sh.strip[0][t] = row0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float x[6], D[16], N[16];
+    se_solve6(&sh.strip[0][1], x);
+    se_se3_exp(x, D);
+    // updatePoseKernel: pose = delta * pose (4x4 product, inner sums left to right)
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c)
+        N[r * 4 + c] = ((D[r * 4 + 0] * P[0 * 4 + c] + D[r * 4 + 1] * P[1 * 4 + c]) + D[r * 4 + 2] * P[2 * 4 + c]) + D[r * 4 + 3] * P[3 * 4 + c];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = s->pose[i];
+    for (int q = 0; q < 16; ++q) sh.pose[q] = N[q];
+    float xn = 0.f;
+    for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
+    sh.conv = sqrtf(xn) < icp_threshold ? 1 : 0;
+  }
+  __syncthreads();
+}
+// state[(j + 1) & 1] as iteration j-1's update leaves it (or a plain copy when that iteration did not run)
+// (first: the frame's first launch -- there is no state yet, `p0` is pose_ on entry; this replaces r03's k_icp_begin launch)
+__device__ __forceinline__ void se_icp_store_state(IcpState* __restrict__ so, const IcpState* __restrict__ si, const IcpShared& sh, bool prev_ran, int prev_level,
+                                                   bool first, const Pose16& p0) {
+  const int t = threadIdx.x;
+  if (first) {
+    if (t < 16) { so->old_pose[t] = p0.m[t]; so->pose[t] = p0.m[t]; so->last_pose[t] = p0.m[t]; }
+    if (t < 32) so->reduce0[t] = 0.f;
+    if (t < 8) so->stop[t] = 0;
+    if (t == 0) { so->iterations = 0; so->tracked = 0; }
+    return;
+  }
+  if (t < 16) { so->old_pose[t] = si->old_pose[t]; so->pose[t] = prev_ran ? sh.pose[t] : si->pose[t]; so->last_pose[t] = prev_ran ? si->pose[t] : si->last_pose[t]; }
+  if (t < 32) so->reduce0[t] = prev_ran ? sh.strip[0][t] : si->reduce0[t];
+  if (t < 8) so->stop[t] = (prev_ran && t == prev_level && sh.conv) ? 1 : si->stop[t];
+  if (t == 0) { so->iterations = si->iterations + (prev_ran ? 1 : 0); so->tracked = si->tracked; }
+}
+#define SE_TRACK_BATCH 5   // pixels of one lane whose loads are in flight together (640x480: ceil(1200 / 256))
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ inVertex,
+                                                              const float* __restrict__ inNormal, const float* __restrict__ refVertex,
+                                                              const float* __restrict__ refNormal, const float* __restrict__ partial_prev,
+                                                              float* __restrict__ partial, TrackArgs a, int prev_level, Pose16 p0) {
+  __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
+  __shared__ IcpShared sh;
+  const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  const bool first = prev_level < 0;                                    // the frame's first launch: the state is `p0`, nothing has converged
+  const bool prev_ran = !first && si->stop[prev_level] == 0;            // (launch j-1 returned before its pixel phase otherwise: nothing to finish)
+  float T[12];
+  int stop_cur = first ? 0 : si->stop[a.level];
+  // this lane's first pixels: their inputs do not depend on the pose, so their loads fly under the prologue
   const int W = a.inW, H = a.inH;
   const int rows = (H - b + 7) / 8;
   const long npx = (long)rows * W;
   const long seg_len = (npx + SE_TRACK_SEGMENTS - 1) / SE_TRACK_SEGMENTS;
   const long lo = g * seg_len, hi = min(npx, (g + 1) * seg_len);
+  f3 inN0[SE_TRACK_BATCH], inV0[SE_TRACK_BATCH];
+  if (!stop_cur) {
+#pragma unroll
+    for (int j = 0; j < SE_TRACK_BATCH; ++j) {
+      const long i = lo + t + (long)j * SE_TRACK_LANES;
+      const long ii = i < hi ? i : lo;
+      const int y = b + 8 * (int)(ii / W), x = (int)(ii % W);
+      inN0[j] = ld3(inNormal, x + y * a.inW);
+      inV0[j] = ld3(inVertex, x + y * a.inW);
+    }
+  }
+  if (prev_ran) {
+    float P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = si->pose[i];
+    se_icp_finalize(sh, partial_prev, P, a.icp_threshold);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = sh.pose[i];
+    if (prev_level == a.level && sh.conv) stop_cur = 1;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = first ? p0.m[i] : si->pose[i];
+  }
+  if (g == 0 && b == 0) se_icp_store_state(so, si, sh, prev_ran, prev_level, first, p0);
+  if (stop_cur) return;                 // the level has converged: the reference's `break`
+  const float R3[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
   float acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-  for (long i = lo + t; i < hi; i += SE_TRACK_LANES) {
-    const int y = b + 8 * (int)(i / W), x = (int)(i % W);
-    TrackData row;
-    row.error = 0.f;
+  for (long base = lo + t; base < hi; base += (long)SE_TRACK_BATCH * SE_TRACK_LANES) {
+    // trackKernel (tracking.cpp:226-302) for SE_TRACK_BATCH pixels, staged so that their loads overlap: same operations per pixel as se_track_pixel
+    f3 inN[SE_TRACK_BATCH], inV[SE_TRACK_BATCH], rN[SE_TRACK_BATCH], rV[SE_TRACK_BATCH], pv[SE_TRACK_BATCH];
+    int res[SE_TRACK_BATCH], ridx[SE_TRACK_BATCH];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) row.J[j] = 0.f;
-    se_track_pixel(row, x, y, inVertex, inNormal, refVertex, refNormal, T, a);
-    se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_rows)
+    for (int j = 0; j < SE_TRACK_BATCH; ++j) {
+      const long i = base + (long)j * SE_TRACK_LANES;
+      const bool live = i < hi;
+      const long ii = live ? i : lo;
+      const int y = b + 8 * (int)(ii / W), x = (int)(ii % W);
+      if (base == lo + t) { inN[j] = inN0[j]; inV[j] = inV0[j]; }     // (fetched before the prologue)
+      else { inN[j] = ld3(inNormal, x + y * a.inW); inV[j] = ld3(inVertex, x + y * a.inW); }
+      res[j] = live ? 0 : 2;              // 2: no pixel
+    }
+#pragma unroll
+    for (int j = 0; j < SE_TRACK_BATCH; ++j) {
+      if (res[j] == 0 && inN[j].x == -2.f) res[j] = -1;
+      pv[j] = m34_mul_h(T, inV[j]);
+      const f3 projectedPos = m34_mul_h(a.view, pv[j]);
+      const float ppx = projectedPos.x / projectedPos.z + 0.5f, ppy = projectedPos.y / projectedPos.z + 0.5f;
+      if (res[j] == 0 && (ppx < 0 || ppx > a.refW - 1 || ppy < 0 || ppy > a.refH - 1)) res[j] = -2;
+      ridx[j] = res[j] == 0 ? cvt_i32(ppx) + cvt_i32(ppy) * a.refW : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < SE_TRACK_BATCH; ++j) { rN[j] = ld3(refNormal, ridx[j]); rV[j] = ld3(refVertex, ridx[j]); }
+#pragma unroll
+    for (int j = 0; j < SE_TRACK_BATCH; ++j) {
+      if (res[j] == 2) continue;
+      TrackData row;
+      row.error = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) row.J[q] = 0.f;
+      row.result = res[j];
+      if (res[j] == 0) {
+        const f3 referenceNormal = rN[j];
+        if (referenceNormal.x == -2.f) row.result = -3;
+        else {
+          const f3 diff = f3_sub(rV[j], pv[j]);
+          const f3 projectedNormal = m3_mul(R3, inN[j]);
+          if (sqrtf(f3_sqnorm(diff)) > a.dist_threshold) row.result = -4;
+          else if (f3_dot(projectedNormal, referenceNormal) < a.normal_threshold) row.result = -5;
+          else {
+            row.result = 1;
+            row.error = f3_dot(referenceNormal, diff);
+            row.J[0] = referenceNormal.x; row.J[1] = referenceNormal.y; row.J[2] = referenceNormal.z;
+            const f3 c = f3_cross(pv[j], referenceNormal);
+            row.J[3] = c.x; row.J[4] = c.y; row.J[5] = c.z;
+          }
+        }
+      }
+      se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_rows)
+    }
   }
 #pragma unroll
   for (int i = 0; i < 32; ++i) lanes[t][i] = acc[i];
@@ -309,42 +464,6 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_track(const IcpState* __
     __syncthreads();
   }
   if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = lanes[0][t];
-}
-
-__global__ __launch_bounds__(256) void k_icp_update(IcpState* __restrict__ s, const float* __restrict__ partial, TrackArgs a) {
-  __shared__ float strip[8][32];
-  if (s->stop[a.level]) return;
-  const int t = threadIdx.x, bb = t >> 5, i = t & 31;
-  {
-    float total = 0.f;
-    for (int gg = 0; gg < SE_TRACK_SEGMENTS; ++gg) total += partial[(bb * SE_TRACK_SEGMENTS + gg) * 32 + i];
-    strip[bb][i] = total;
-  }
-  __syncthreads();
-  if (t < 32) {
-    float row0 = strip[0][t];
-    for (int b2 = 1; b2 < 8; ++b2) row0 += strip[b2][t];
-    strip[0][t] = row0;
-    s->reduce0[t] = row0;
-  }
-  __syncthreads();
-  if (t == 0) {
-    float x[6], D[16], P[16], N[16];
-    se_solve6(&strip[0][1], x);
-    se_se3_exp(x, D);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { P[q] = s->pose[q]; s->last_pose[q] = P[q]; }
-    // updatePoseKernel: pose = delta * pose (4x4 product, inner sums left to right)
-    for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c)
-        N[r * 4 + c] = ((D[r * 4 + 0] * P[0 * 4 + c] + D[r * 4 + 1] * P[1 * 4 + c]) + D[r * 4 + 2] * P[2 * 4 + c]) + D[r * 4 + 3] * P[3 * 4 + c];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) s->pose[q] = N[q];
-    float xn = 0.f;
-    for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
-    if (sqrtf(xn) < a.icp_threshold) s->stop[a.level] = 1;
-    s->iterations = s->iterations + 1;
-  }
 }
 
 // tracking_result_ (what renderTrackKernel shows and se_hip_download_track returns) as the reference leaves it after the frame's last
@@ -366,16 +485,38 @@ __global__ __launch_bounds__(256) void k_icp_rows(const IcpState* __restrict__ s
   if (row.result == 1) { dst.error = row.error; for (int j = 0; j < 6; ++j) dst.J[j] = row.J[j]; }
 }
 
-// checkPoseKernel (tracking.cpp:320-334) + the one record the host reads per frame (pinned memory, sequence word last)
-__global__ void k_icp_finish(IcpState* __restrict__ s, IcpHostRecord* __restrict__ host, int W, int H, unsigned seq) {
-  if (threadIdx.x != 0) return;
-  const float* v = s->reduce0;
+// The last iteration's prologue work (see k_icp_iter) + checkPoseKernel (tracking.cpp:320-334) + the one record the host reads per
+// frame (pinned memory, sequence word last).  One workgroup of SE_TRACK_LANES threads.
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ partial_prev,
+                                                                IcpHostRecord* __restrict__ host, int W, int H, unsigned seq, float icp_threshold, int prev_level, Pose16 p0) {
+  __shared__ IcpShared sh;
+  const int t = threadIdx.x;
+  if (prev_level < 0) {   // no iteration was enqueued at all (every pyramid entry 0): the record is the entry pose, sums zero -> rejected, as in the reference
+    se_icp_store_state(so, si, sh, false, prev_level, true, p0);
+    if (t != 0) return;
+    for (int i = 0; i < 16; ++i) host->pose[i] = p0.m[i];
+    for (int i = 0; i < 32; ++i) host->reduce0[i] = 0.f;
+    host->iterations = 0; host->tracked = 0;
+    __threadfence_system();
+    *(volatile unsigned*)&host->seq = seq;
+    return;
+  }
+  const bool prev_ran = si->stop[prev_level] == 0;
+  if (prev_ran) {
+    float P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = si->pose[i];
+    se_icp_finalize(sh, partial_prev, P, icp_threshold);
+  }
+  se_icp_store_state(so, si, sh, prev_ran, prev_level, false, p0);
+  if (t != 0) return;
+  const float* v = prev_ran ? sh.strip[0] : si->reduce0;     // reduction_output_ of the last iteration that ran
   const bool bad = ((double)sqrtf(v[0] / v[28]) > 2e-2) || (v[28] / (W * H) < 0.15f);
-  for (int i = 0; i < 16; ++i) host->pose[i] = bad ? s->old_pose[i] : s->pose[i];
+  for (int i = 0; i < 16; ++i) host->pose[i] = bad ? si->old_pose[i] : (prev_ran ? sh.pose[i] : si->pose[i]);
   for (int i = 0; i < 32; ++i) host->reduce0[i] = v[i];
-  host->iterations = s->iterations;
+  host->iterations = si->iterations + (prev_ran ? 1 : 0);
   host->tracked = bad ? 0 : 1;
-  s->tracked = bad ? 0 : 1;
+  so->tracked = bad ? 0 : 1;     // (se_icp_store_state's own store to this word was this thread's, earlier in program order)
   __threadfence_system();
   *(volatile unsigned*)&host->seq = seq;
 }
