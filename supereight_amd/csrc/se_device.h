@@ -44,6 +44,8 @@ struct DevMap {
   uint32_t* tab;
   uint32_t off[SE_MAX_LEVELS];
   uint32_t* occ;                  // occupancy bits in heap order: octant (level l, Morton index c) is bit (1 << 3l) | c
+  uint32_t* lbits;                // one bit per cell of the block grid, in block_linear order: 'a block is allocated here' (the raycast's march asks it
+                                  // before it touches a brick or the index: 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 -- L2-resident)
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)

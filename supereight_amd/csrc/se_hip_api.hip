@@ -139,7 +139,7 @@ struct se_hip_pipeline {
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
-  size_t occ_words = 0;
+  size_t occ_words = 0, lbits_words = 0;
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
@@ -401,6 +401,7 @@ void reset_map_state(se_hip_pipeline* p) {
   DevMap& m = p->map;
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.lbits, 0, p->lbits_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
   hipMemsetAsync(m.npos, 0, p->cap_nodes * sizeof(uint32_t), p->stream);
@@ -484,9 +485,13 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   // Pooled mode (max_blocks > 0, or a grid that does not fit): max_blocks bricks behind the index.
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  bool dense = cfg->max_blocks <= 0 && cells * 4096 <= free_b / 3;
+  // r04: a dense grid is the default only while it costs <= 16 GiB (<= 1024^3).  Beyond that (2048^3: 64 GiB for a ~2 GB payload) the
+  // default is the pooled layout with room for 1/20 of the grid's cells -- 3.2 GiB of bricks at 2048^3, 7x the blocks the benchmark stream
+  // allocates there; a pool that runs out is reported (SE_HIP_E_CAPACITY), max_blocks raises it.  Measured with the lean pooled march
+  // (profiles/r04h_pooled_vs_dense.log): pooled is 2.6 % / 3.0 % behind dense in frames/s at 1024^3 / 2048^3 and 25 % behind at 512^3.
+  bool dense = cfg->max_blocks <= 0 && cells * 4096 <= free_b / 3 && cells * 4096 <= ((size_t)16 << 30);
   if (const char* ev = std::getenv("SE_HIP_DENSE")) dense = std::atoi(ev) != 0 && cells * 4096 <= free_b / 2;
-  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : (dense ? cells : std::min(cells, (size_t)1 << 21));
+  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : (dense ? cells : std::max((size_t)1 << 16, ((cells / 20 + 4095) / 4096) * 4096));
   cap = std::min(cap, cells);
   m.dense = dense ? 1 : 0;
   const size_t slots = dense ? cells : cap;   // voxel bricks / active flags
@@ -522,6 +527,8 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   }
   ALLOC(m.tab, p->tab_entries * sizeof(uint32_t));
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
+  p->lbits_words = (cells + 31) / 32;
+  ALLOC(m.lbits, p->lbits_words * sizeof(uint32_t));
 #if SE_BRICK_STRIDE == 1024
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
   m.vy = m.vx + 512;
@@ -594,7 +601,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
+  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);

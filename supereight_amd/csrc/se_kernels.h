@@ -70,6 +70,7 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
     m.bpos[idx] = bp;
     m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
     occ_set(m, level, x, y, z);
+    { const uint32_t lin = block_linear(m, x, y, z); atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u)); }   // (never deferred: a reader that sees the bit early finds PENDING or a brick of initValue())
     atomicExch(e, slot + 1u);
   } else {
     const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
@@ -1681,6 +1682,9 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 #ifndef SE_MARCH_LEAN
 #define SE_MARCH_LEAN 1
 #endif
+#ifndef SE_MARCH_PROBE
+#define SE_MARCH_PROBE 1   // dense maps > 512^3: leaf-bitmap probe in front of brick reads while the march is in unobserved space (se_cast_ray_sdf_lean)
+#endif
 __device__ __forceinline__ int se_cvt_hw(float f) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
 template <bool O32> struct SeDense;
 template <> struct SeDense<true> {     // byte-offset terms, 32 bit
@@ -1797,12 +1801,30 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
   float S = a.largestep;
   bool done = false;
   bool band = f_t < 1.f;   // the last value seen was inside the truncation band: the next sample probably wants its interpolated value
+  bool unobs = false;      // the last consumed sample had weight 0 (unobserved space)
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
     const f3 q0 = position;
     const f3 q1 = f3_add(q0, f3_scale(S, dir));
-    const SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
-    const float x0 = A::ldx(m, s0.vi), y0 = A::ldy(m, s0.vi), x1 = A::ldx(m, s1.vi), y1 = A::ldy(m, s1.vi);
+    SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
+    float x0, y0, x1, y1;
+    bool probed = false;
+    if constexpr (SE_MARCH_PROBE && !O32) {
+     if (unobs) {
+      probed = true;
+      // Volumes > 512^3: the march is latency-bound on cold brick lines, and 43 % of its samples lie in blocks that were
+      // never allocated -- whose bricks the dense grid backs with real memory nobody else touches.  While the march walks through
+      // unobserved space (the last value had weight 0) it asks the leaf bitmap first (L2-resident) and reads a brick only where a
+      // block exists; an absent block reads as initValue(), which is what its brick holds.
+      const uint32_t w0 = m.lbits[s0.vi.blk >> 5], w1 = m.lbits[s1.vi.blk >> 5];
+      s0.in = s0.in && ((w0 >> (s0.vi.blk & 31u)) & 1u);
+      s1.in = s1.in && ((w1 >> (s1.vi.blk & 31u)) & 1u);
+      x0 = fc.init_x; y0 = fc.init_y; x1 = fc.init_x; y1 = fc.init_y;
+      if (s0.in) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); }
+      if (s1.in) { x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
+     }
+    }
+    if (!probed) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
     SeCell<O32> cell0;
     float cv0[8];
     bool have0 = false;
@@ -1820,6 +1842,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
       if (STATS) ++rc.n_get;
       const bool ok = i ? s1.in : s0.in;
       const float dx = ok ? (i ? x1 : x0) : fc.init_x, dy = ok ? (i ? y1 : y0) : fc.init_y;
+      unobs = dy == 0;
       if (dy == 0) {
         stepsize = a.largestep;
         position = f3_add(position, f3_scale(stepsize, dir));
@@ -1852,6 +1875,138 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
     hx = r.x; hy = r.y; hz = r.z; hw = t;
   }
 }
+// ---- the same for pooled bricks (the north-star layout: bump-allocated bricks behind the index).  A sample's block entry comes from
+// tab[]; while the march is in unobserved space it asks the leaf bitmap first, so that a block that was never allocated costs a bit test
+// in an L2-resident array instead of a line of the 8 / 64 MB leaf index.  The entry of the previous sample's block is kept (most steps
+// stay in or next to it).  interp / grad of a hit go through the generic forms (eight / 2x2x2 block look-ups), as before.
+struct SePSample { uint32_t e, loc; int bx, by, bz; };
+struct SePCache { uint32_t lin, e; };
+template <bool PROBE>
+__device__ __forceinline__ SePSample se_sample_pooled(const DevMap& m, const RayArgs& a, f3 q, SePCache& c, bool unobs) {
+  const int ix = se_cvt_hw(a.inv_voxel * q.x), iy = se_cvt_hw(a.inv_voxel * q.y), iz = se_cvt_hw(a.inv_voxel * q.z);
+  const bool in = (uint32_t)(ix | iy | iz) < (uint32_t)m.size;
+  SePSample s;
+  s.bx = ix >> 3; s.by = iy >> 3; s.bz = iz >> 3;
+  s.loc = ((uint32_t)ix & 7u) | (((uint32_t)iy & 7u) << 3) | (((uint32_t)iz & 7u) << 6);
+  s.e = 0u;
+  if (in) {
+    const uint32_t lin = block_linear(m, s.bx, s.by, s.bz);
+    if (lin == c.lin) s.e = c.e;
+    else {
+      bool present = true;
+      if (PROBE && unobs) present = (m.lbits[lin >> 5] >> (lin & 31u)) & 1u;
+      uint32_t e = 0u;
+      if (present) { e = m.tab[m.leaf_off + lin]; e = e == SE_PENDING ? 0u : e; }   // (PENDING: see se_block_entry)
+      c.lin = lin; c.e = e;
+      s.e = e;
+    }
+  }
+  return s;
+}
+__device__ __forceinline__ size_t se_pooled_index(const SePSample& s) { return ((size_t)(s.e ? s.e - 1u : 0u) << 10) | s.loc; }
+template <bool STATS>
+__device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
+                                                       BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  if (!(tnear < tfar)) return;
+  float t = tnear;
+  float stepsize = a.largestep;
+  f3 position = f3_add(org, f3_scale_r(dir, t));
+  float f_t = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, position), c);
+  if (STATS) ++rc.n_interp;
+  float f_tt = 0;
+  if (!(f_t > 0)) return;
+  float S = a.largestep;
+  bool done = false, unobs = false;
+  SePCache pc = {0xFFFFFFFFu, 0u};
+  for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+    ++rc.n_batch;
+    const f3 q0 = position;
+    const f3 q1 = f3_add(q0, f3_scale(S, dir));
+    const SePSample s0 = se_sample_pooled<true>(m, a, q0, pc, unobs), s1 = se_sample_pooled<true>(m, a, q1, pc, unobs);
+    const size_t i0 = se_pooled_index(s0), i1 = se_pooled_index(s1);
+    const float x0 = m.vx[i0], y0 = m.vx[i0 + 512], x1 = m.vx[i1], y1 = m.vx[i1 + 512];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!(t < tfar)) { done = true; break; }
+      if (STATS) ++rc.n_get;
+      const SePSample& sm = i ? s1 : s0;
+      const float dx = sm.e ? (i ? x1 : x0) : fc.init_x, dy = sm.e ? (i ? y1 : y0) : fc.init_y;
+      unobs = dy == 0;
+      if (dy == 0) {
+        stepsize = a.largestep;
+        position = f3_add(position, f3_scale(stepsize, dir));
+      } else {
+        f_tt = dx;
+        if (f_tt < 0.1f && f_tt >= -0.5f) {   // (double)f_tt <= 0.1
+          c.bx = sm.bx; c.by = sm.by; c.bz = sm.bz; c.e = sm.e;      // the block of this sample as the look-up hint
+          f_tt = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, position), c);
+          if (STATS) ++rc.n_interp;
+        }
+        if (f_tt < 0) { done = true; break; }
+        stepsize = fmaxf(f_tt * a.mu, a.step);
+        position = f3_add(position, f3_scale(stepsize, dir));
+        f_t = f_tt;
+      }
+      t += stepsize;
+      if (stepsize != S) { S = stepsize; break; }
+    }
+  }
+  if (f_tt < 0) {
+    t = t + stepsize * f_tt / (f_t - f_tt);
+    const f3 r = f3_add(org, f3_scale_r(dir, t));
+    hx = r.x; hy = r.y; hz = r.z; hw = t;
+  }
+}
+template <bool STATS>
+__device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
+                                                      BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  if (!(tnear < tfar)) return;
+  float t = tnear;
+  const float stepsize = a.step;
+  float f_t = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
+  if (STATS) ++rc.n_interp;
+  float f_tt = 0;
+  if (!(f_t <= 0.f)) return;
+  bool done = false;
+  SePCache pc = {0xFFFFFFFFu, 0u};
+  for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
+    ++rc.n_batch;
+    float tt[SE_SPEC_OF];
+    f3 q[SE_SPEC_OF];
+    SePSample sm[SE_SPEC_OF];
+    float qx[SE_SPEC_OF], qy[SE_SPEC_OF];
+    tt[0] = t;
+#pragma unroll
+    for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) { q[i] = f3_add(org, f3_scale_r(dir, tt[i])); sm[i] = se_sample_pooled<false>(m, a, q[i], pc, false); }
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) { const size_t vi = se_pooled_index(sm[i]); qx[i] = m.vx[vi]; qy[i] = m.vx[vi + 512]; }
+    bool stop = false;
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) {
+      if (stop) continue;
+      t = tt[i];
+      if (!(t < tfar)) { done = true; stop = true; continue; }
+      if (STATS) ++rc.n_get;
+      const float dx = sm[i].e ? qx[i] : fc.init_x, dy = sm[i].e ? qy[i] : fc.init_y;
+      if (dx > -100.f && dy > 0.f) {
+        c.bx = sm[i].bx; c.by = sm[i].by; c.bz = sm[i].bz; c.e = sm[i].e;
+        f_tt = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
+        if (STATS) ++rc.n_interp;
+      }
+      if (f_tt > 0.f) { done = true; stop = true; continue; }
+      f_t = f_tt;
+    }
+    if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
+  }
+  if (f_tt > 0.f) {
+    t = t - stepsize * (f_tt - 0.f) / (f_tt - f_t);
+    const f3 r = f3_add(org, f3_scale_r(dir, t));
+    hx = r.x; hy = r.y; hz = r.z; hw = t;
+  }
+}
+
 // raycast(const Volume<OFusion>&, ...) (se_denseslam/src/bfusion/rendering_impl.hpp:35-68) on the dense grid with the lean addressing
 // above; same float operations in the same order as the generic form in se_cast_ray
 template <bool STATS, bool O32>
@@ -1908,6 +2063,8 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
                                             BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
   if (SE_MARCH_LEAN && !OFUSION && DENSE) { se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
   if (SE_MARCH_LEAN && OFUSION && DENSE) { se_cast_ray_of_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
+  if (SE_MARCH_LEAN && !OFUSION && !DENSE) { se_cast_ray_sdf_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
+  if (SE_MARCH_LEAN && OFUSION && !DENSE) { se_cast_ray_of_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
   unsigned long long& n_get = rc.n_get;
   unsigned long long& n_interp = rc.n_interp;
   {
