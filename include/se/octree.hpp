@@ -8,12 +8,16 @@
  * voxel_block_[512] x-fastest, active_), paged in two buffers in key order.  The read-only part of the reference's
  * interface is provided with the reference's semantics:
  *   size(), dim(), get(x,y,z), get_fine(x,y,z), fetch(x,y,z), fetch_octant(x,y,z,depth)   (octree.hpp:340-478)
+ *   interp(pos, select), grad(pos), grad(pos, select)                                     (octree.hpp:541-563, 565-737; r04)
+ *     -- what the reference's planning / collision users sample a map with.  `pos` is any 3-vector type with operator()(int)
+ *     (Eigen::Vector3f in the reference; Eigen is not a dependency of this header), grad returns the same type.
  *   getBlockBuffer() / getNodesBuffer()-style access, save(filename)                        (octree.hpp:898-914)
  * Integration, allocation and ray casting stay on the device; this object is a snapshot.
  */
 #ifndef SE_HIP_OCTREE_HPP
 #define SE_HIP_OCTREE_HPP
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <memory>
@@ -119,9 +123,84 @@ template <typename T> class Octree {
     return static_cast<VoxelBlock<T>*>(n)->data(x, y, z);
   }
   value_type get_fine(const int x, const int y, const int z) const {
+    /* outside [0, size)^3 the reference's bit walk lands in whatever block the low bits name and reads past its array; here such a
+     * voxel is "not allocated" (the answer the reference gives wherever it is defined) */
+    if ((unsigned)x >= (unsigned)size_ || (unsigned)y >= (unsigned)size_ || (unsigned)z >= (unsigned)size_) return voxel_traits<T>::initValue();
     VoxelBlock<T>* b = fetch(x, y, z);
     return b ? b->data(x, y, z) : voxel_traits<T>::initValue();
   }
+
+  /* Octree::get(x, y, z, cached) (octree.hpp:379-408): the voxel from `cached` if that block contains it, else the tree walk of get_fine */
+  value_type get(const int x, const int y, const int z, VoxelBlock<T>* cached) const {
+    if (cached) {
+      const int* lo = cached->coordinates();
+      if (x >= lo[0] && x <= lo[0] + (int)blockSide - 1 && y >= lo[1] && y <= lo[1] + (int)blockSide - 1 && z >= lo[2] && z <= lo[2] + (int)blockSide - 1)
+        return cached->data(x, y, z);
+    }
+    return get_fine(x, y, z);
+  }
+
+  /* Octree::interp (octree.hpp:541-563) with gather_points (interpolation/interp_gather.hpp:44-237): trilinear blend of the eight
+   * voxels around pos (voxel units).  Each corner comes from the block that holds it; the corners of a block that is not allocated
+   * read as empty() -- except when the cell straddles a block boundary on all three axes, where the reference goes through
+   * get_fine() and a missing block reads as initValue(). */
+  template <typename Vec3, typename FieldSelect>
+  float interp(const Vec3& pos, FieldSelect select) const {
+    const float fl[3] = {floor_(pos(0)), floor_(pos(1)), floor_(pos(2))};
+    const float f[3] = {pos(0) - fl[0], pos(1) - fl[1], pos(2) - fl[2]};
+    const int lower[3] = {imax(to_int(fl[0]), 0), imax(to_int(fl[1]), 0), imax(to_int(fl[2]), 0)};
+    const bool cross[3] = {lower[0] % (int)blockSide == (int)blockSide - 1, lower[1] % (int)blockSide == (int)blockSide - 1,
+                           lower[2] % (int)blockSide == (int)blockSide - 1};
+    const bool all_cross = cross[0] && cross[1] && cross[2];
+    float p[8];
+    for (int k = 0; k < 8; ++k) {
+      const int d[3] = {k & 1, (k >> 1) & 1, k >> 2};
+      const int x = lower[0] + d[0], y = lower[1] + d[1], z = lower[2] + d[2];
+      if (all_cross) { p[k] = select(get_fine(x, y, z)); continue; }
+      /* the block gather_points fetches for this corner: the base block, stepped across only on the axes that straddle */
+      VoxelBlock<T>* b = fetch(lower[0] + (cross[0] ? d[0] : 0), lower[1] + (cross[1] ? d[1] : 0), lower[2] + (cross[2] ? d[2] : 0));
+      const int* lo = b ? b->coordinates() : nullptr;
+      const bool inside = b && x >= lo[0] && x < lo[0] + (int)blockSide && y >= lo[1] && y < lo[1] + (int)blockSide && z >= lo[2] && z < lo[2] + (int)blockSide;
+      p[k] = inside ? select(b->data(x, y, z)) : select(voxel_traits<T>::empty());
+    }
+    return (((p[0] * (1 - f[0]) + p[1] * f[0]) * (1 - f[1]) + (p[2] * (1 - f[0]) + p[3] * f[0]) * f[1]) * (1 - f[2]) +
+            ((p[4] * (1 - f[0]) + p[5] * f[0]) * (1 - f[1]) + (p[6] * (1 - f[0]) + p[7] * f[0]) * f[1]) * f[2]);
+  }
+
+  /* Octree::grad (octree.hpp:652-737): central differences of the trilinearly blended field, same term order; the result is scaled by
+   * 0.5 * dim / size.  grad(pos) without a selector (octree.hpp:565-650) selects .x, as the reference does. */
+  template <typename Vec3, typename FieldSelect>
+  Vec3 grad(const Vec3& pos, FieldSelect select) const {
+    const float fl[3] = {floor_(pos(0)), floor_(pos(1)), floor_(pos(2))};
+    const float fx = pos(0) - fl[0], fy = pos(1) - fl[1], fz = pos(2) - fl[2];
+    const int base[3] = {to_int(fl[0]), to_int(fl[1]), to_int(fl[2])};
+    const int hi = size_ - 1;
+    int X[4], Y[4], Z[4];   /* lower_lower, lower_upper (= lower), upper_lower (= upper), upper_upper */
+    X[0] = imax(base[0] - 1, 0); X[1] = imax(base[0], 0); X[2] = imin(base[0] + 1, hi); X[3] = imin(base[0] + 2, hi);
+    Y[0] = imax(base[1] - 1, 0); Y[1] = imax(base[1], 0); Y[2] = imin(base[1] + 1, hi); Y[3] = imin(base[1] + 2, hi);
+    Z[0] = imax(base[2] - 1, 0); Z[1] = imax(base[2], 0); Z[2] = imin(base[2] + 1, hi); Z[3] = imin(base[2] + 2, hi);
+    VoxelBlock<T>* n = fetch(base[0], base[1], base[2]);
+    auto G = [&](int xi, int yi, int zi) { return select(get(X[xi], Y[yi], Z[zi], n)); };
+    float g[3];
+    g[0] = (((G(2, 1, 1) - G(0, 1, 1)) * (1 - fx) + (G(3, 1, 1) - G(1, 1, 1)) * fx) * (1 - fy) +
+            ((G(2, 2, 1) - G(0, 2, 1)) * (1 - fx) + (G(3, 2, 1) - G(1, 2, 1)) * fx) * fy) * (1 - fz) +
+           (((G(2, 1, 2) - G(0, 1, 2)) * (1 - fx) + (G(3, 1, 2) - G(1, 1, 2)) * fx) * (1 - fy) +
+            ((G(2, 2, 2) - G(0, 2, 2)) * (1 - fx) + (G(3, 2, 2) - G(1, 2, 2)) * fx) * fy) * fz;
+    g[1] = (((G(1, 2, 1) - G(1, 0, 1)) * (1 - fx) + (G(2, 2, 1) - G(2, 0, 1)) * fx) * (1 - fy) +
+            ((G(1, 3, 1) - G(1, 1, 1)) * (1 - fx) + (G(2, 3, 1) - G(2, 1, 1)) * fx) * fy) * (1 - fz) +
+           (((G(1, 2, 2) - G(1, 0, 2)) * (1 - fx) + (G(2, 2, 2) - G(2, 0, 2)) * fx) * (1 - fy) +
+            ((G(1, 3, 2) - G(1, 1, 2)) * (1 - fx) + (G(2, 3, 2) - G(2, 1, 2)) * fx) * fy) * fz;
+    g[2] = (((G(1, 1, 2) - G(1, 1, 0)) * (1 - fx) + (G(2, 1, 2) - G(2, 1, 0)) * fx) * (1 - fy) +
+            ((G(1, 2, 2) - G(1, 2, 0)) * (1 - fx) + (G(2, 2, 2) - G(2, 2, 0)) * fx) * fy) * (1 - fz) +
+           (((G(1, 1, 3) - G(1, 1, 1)) * (1 - fx) + (G(2, 1, 3) - G(2, 1, 1)) * fx) * (1 - fy) +
+            ((G(1, 2, 3) - G(1, 2, 1)) * (1 - fx) + (G(2, 2, 3) - G(2, 2, 1)) * fx) * fy) * fz;
+    const float scale = 0.5f * dim_ / size_;
+    Vec3 out = pos;
+    out(0) = scale * g[0]; out(1) = scale * g[1]; out(2) = scale * g[2];
+    return out;
+  }
+  template <typename Vec3>
+  Vec3 grad(const Vec3& pos) const { return grad(pos, [](const value_type& v) { return v.x; }); }
 
   /* Octree::save (octree.hpp:898-914; io/se_serialise.hpp:54-86): int size, float dim, size_t n, nodes {code, side, value_[8]},
    * size_t n, blocks {code, coordinates, voxel_block_[512]} -- written field by field so that the value_type padding of the
@@ -170,6 +249,11 @@ template <typename T> class Octree {
   }
 
  private:
+  /* floor / float -> int as the reference's build evaluates them (math::floorf + Eigen cast<int>: truncation; out of int range: INT_MIN, x86) */
+  static float floor_(float v) { return std::floor(v); }
+  static int to_int(float v) { return (v > -2147483904.f && v < 2147483648.f) ? (int)v : (int)0x80000000; }
+  static int imax(int a, int b) { return a > b ? a : b; }
+  static int imin(int a, int b) { return a < b ? a : b; }
   static void put(FILE* f, const SDF& v) { std::fwrite(&v.x, 4, 1, f); std::fwrite(&v.y, 4, 1, f); }
   template <typename V> static void put(FILE* f, const V& v) { const uint32_t pad = 0; std::fwrite(&v.x, 4, 1, f); std::fwrite(&pad, 4, 1, f); std::fwrite(&v.y, 8, 1, f); }
   static int coord_of(key_t code, int axis) {   /* compact the bits 3i + axis of the Morton code */

@@ -85,10 +85,39 @@ def test_640x480_512_properties(field, mu, frames):
     p.close(); q.close()
 
 
+def test_1280x960_2048_full_size_oracle_parity():
+    """BASELINE.json configs[3] at its FULL size against the oracle (parity had only been run at 160x120 -> 2048^3):
+    1280x960 -> 2048^3, frames 0..3 -- 402 k blocks allocated by frame 0, one raycast (frame 3) -- in the default layout of that size
+    (pooled bricks).  Block / node sets, every voxel, active flags, hit mask, vertices and normals bit for bit.  ~20 s of oracle."""
+    from tests.parity_util import compare_maps, compare_raycast, run_both
+    W, H, N, dim, mu, frames = 1280, 960, 2048, 4.8, 0.1, 4
+    cpu, gpu, recs = run_both(SDF, W, H, N, dim, mu, frames)
+    m = compare_maps(cpu, gpu)
+    assert m["same_block_set"] and m["same_node_set"] and m["blocks_cpu"] > 350_000, m
+    assert m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0 and m["node_x_mismatch"] == 0 and m["node_y_mismatch"] == 0, m
+    rays = [r for r in recs if r["raycast"]]
+    assert len(rays) == 1
+    r = compare_raycast(rays[0], dim / N)
+    print("full-size 2048^3 parity:", {k: m[k] for k in ("blocks_cpu", "nodes_cpu", "voxels")}, r)
+    assert r["hits_gpu"] > 0.8 * W * H and r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, r
+    cpu.close(); gpu.close()
+
+
 def test_1280x960_2048_properties():
-    """BASELINE.json configs[3] geometry on one GPU: 64 GiB dense brick grid vs a 1 M-block pool."""
+    """BASELINE.json configs[3] geometry on one GPU: the 64 GiB dense brick grid (forced: the default layout of this size is pooled
+    since r04) vs the default pool vs a 1 M-block pool."""
+    import os
     W, H, N, dim, mu, frames = 1280, 960, 2048, 4.8, 0.1, 5
-    p = run(SDF, W, H, N, dim, mu, frames)
+    os.environ["SE_HIP_DENSE"] = "1"
+    try:
+        p = run(SDF, W, H, N, dim, mu, frames)
+    finally:
+        del os.environ["SE_HIP_DENSE"]
+    d0 = run(SDF, W, H, N, dim, mu, frames)          # default layout: pooled, room for 1/20 of the grid's cells
+    assert d0.counts() == p.counts()
+    v0, n0 = d0.vertex_normal(); vp, np_ = p.vertex_normal()
+    assert (v0.view(np.uint32) == vp.view(np.uint32)).all() and (n0.view(np.uint32) == np_.view(np.uint32)).all()
+    d0.close()
     nb, nn = p.counts()
     assert 350_000 < nb < 600_000                                     # SURVEY: ~402 k blocks after frame 0
     v, n = p.vertex_normal()
