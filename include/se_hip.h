@@ -186,9 +186,13 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, f
 /* ---- "next" row f-2: bool DenseSLAMSystem::tracking(const Vector4f& k, float icp_threshold,
  *      unsigned tracking_rate, unsigned frame)  (DenseSLAMSystem.h:173, DenseSLAMSystem.cpp:143-189):
  *      half-sample pyramid of the current depth image, depth2vertex / vertex2normal per level, ICP against vertex_ /
- *      normal_ of the last se_hip_raycast, checkPoseKernel.  The ICP loop is device-resident: one launch per iteration does
- *      trackKernel + reduceKernel + updatePoseKernel (6x6 Cholesky solve, SE3 exponential, pose update, convergence test);
- *      the call waits on the host once, for the final pose.
+ *      normal_ of the last se_hip_raycast, checkPoseKernel.  The ICP loop is device-resident: one launch per iteration
+ *      (k_icp_iter: the previous iteration's final sums + updatePoseKernel -- 6x6 Cholesky solve, SE3 exponential, pose update,
+ *      convergence test -- as a prologue, then trackKernel + reduceKernel's partial sums), k_icp_finish (the last iteration's
+ *      sums and update, checkPoseKernel, the host record) and k_icp_rows (tracking_result_); the call waits on the host once.
+ *      A row-sharded handle must have the peers' rows of vertex_ / normal_ (se_hip_gather_images or se_hip_apply_image_tiles
+ *      after the raycast): SE_HIP_E_INVALID otherwise.  se_hip_download_track: `result` of every pixel and error / J of the
+ *      accepted ones are the reference's; its rejected pixels keep leftovers of earlier iterations there, zeros here.
  *      pose_inout = pose_ (updated in place; restored if the check fails); pyramid = iterations per
  *      level, finest first (default {10, 5, 4}).  Returns 1 = tracked, 0 = gated off or rejected. */
 int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame,

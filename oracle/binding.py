@@ -110,6 +110,7 @@ def _declare(lib):
         "so_num_threads": (i32, []),
         "so_set_num_threads": (None, [i32]),
         "so_set_sophus_quat": (None, [i32]),
+        "so_set_libm_sincos": (None, [i32]),
         "so_fp_contract": (i32, []),
     }
     for name, (res, args) in sig.items():

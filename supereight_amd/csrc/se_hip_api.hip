@@ -108,6 +108,7 @@ struct se_hip_pipeline {
   bool gate_armed = false;         // a sweep was enqueued that no scan / upload has waited for yet
   bool gate_followed = false;      // ... and a raycast was enqueued behind it
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
+  bool images_complete = true; // vertex_ / normal_ hold every row of the last raycast (a row-sharded replica: only after se_hip_apply_image_tiles / se_hip_gather_images)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool scan_on_side = false;   // stream the LAST allocation scan ran on: se_hip_alloc_exchange / se_hip_alloc_commit follow it
   bool upload_on_side = false; // the current depth image was uploaded on `side`
@@ -1097,6 +1098,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (int r = check_overflow(p)) return r;
   if (int r = join_scan(p)) return r;
   std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
+  p->images_complete = !p->sharded;   // a row-sharded replica has just overwritten its own rows only
   const DevMap& m = p->map;
   RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
   if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
@@ -1159,6 +1161,7 @@ int se_hip_apply_image_tiles(se_hip_pipeline* p, const void* recv_device, int32_
     HIP_TRY(hipMemcpyAsync((char*)p->vertex + (size_t)b * row_bytes, src, (size_t)(e - b) * row_bytes, hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync((char*)p->normal + (size_t)b * row_bytes, src + (size_t)max_rows * row_bytes, (size_t)(e - b) * row_bytes, hipMemcpyDeviceToDevice, p->stream));
   }
+  p->images_complete = true;   // (the copies are on the main stream, in front of any later se_hip_track)
   return SE_HIP_OK;
 }
 int se_hip_gather_images(se_hip_pipeline* p, void* send_device, void* recv_device, int32_t max_rows, const int32_t* row_begin, const int32_t* row_end) {
@@ -1193,6 +1196,9 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   if (int r = check(p)) return r;
   if (!k || !pose_cm || !pyramid || n_levels < 1 || n_levels > 8 || tracking_rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (frame % tracking_rate != 0) return 0;   // DenseSLAMSystem.cpp:146
+  // the ICP reads the WHOLE of vertex_ / normal_; a row-sharded replica holds only its own rows of the last raycast until
+  // the peers' tiles have been applied -- tracking against the stale rows of an earlier frame would be silent garbage
+  if (p->sharded && !p->images_complete) return fail(SE_HIP_E_INVALID, "row-sharded handle: se_hip_gather_images / se_hip_apply_image_tiles must follow the raycast before se_hip_track");
   if (int r = join_scan(p)) return r;
   const int W = p->cfg.width, H = p->cfg.height;
   if ((W >> (n_levels - 1)) < 1 || (H >> (n_levels - 1)) < 1) return fail(SE_HIP_E_INVALID, "too many pyramid levels");

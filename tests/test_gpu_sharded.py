@@ -380,6 +380,10 @@ def test_sharded_tracking_sees_the_full_images(R, H):
             single.setPose(start)
             ok_s = single.tracking(stream.k, 1e-5, 1, f)
             td_s, red_s, it_s = single.track_data()
+            # a row-sharded handle refuses to track against images of which it only holds its own rows
+            from supereight_amd.pipeline import SeHipError
+            with pytest.raises(SeHipError, match="row-sharded"):
+                reps[0].tracking(stream.k, 1e-5, 1, f)
             for r, p in enumerate(reps):
                 p.pack_image_tile(tiles[r].data_ptr(), max_rows)
             for p in reps:

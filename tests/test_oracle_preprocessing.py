@@ -42,3 +42,48 @@ def test_bilateral_filter_constant_image_and_edges():
     d[:, 8:] = 1.75
     out = oracle_bilateral_filter(d)
     assert np.abs(out - d).max() < 1e-4
+
+
+def test_sincos_redefinition_stays_within_a_bound_of_libm_arithmetic():
+    """ADVICE r03: the parity oracle (and the device) DEFINE the sin / cos inside Sophus::SE3f::exp as the correctly rounded values,
+    where the reference calls its C library's sinf / cosf (1 ulp off on a fraction of a percent of arguments).  The same closed SLAM
+    loop -- tracking -> integration -> raycasting, 40 tracked frames of the room stream at 160x120 -> 128^3 -- is run with both
+    definitions; the tracked poses must stay within 2e-6 m / 2e-7 per rotation entry of each other at every frame, which is what
+    ties the bit-exact ICP gate of tests/test_gpu_tracking.py to the reference's arithmetic by a measured number."""
+    from oracle.binding import SDF, OraclePipeline, load, oracle_tracking
+    from supereight_amd.synthetic import SyntheticStream
+    W, H, N, dim, mu, frames = 160, 120, 128, 2.4, 0.1, 44
+    lib = load()
+
+    def loop(libm):
+        lib.so_set_libm_sincos(1 if libm else 0)
+        try:
+            s = SyntheticStream(W, H, dim)
+            o = OraclePipeline(SDF, N, dim, W, H)
+            pose = s.pose(0).copy()
+            v = n = rp = None
+            poses, accepted = [], 0
+            for f in range(frames):
+                d = s.depth(f)
+                if f >= 4:
+                    ok, pose, _, _, _ = oracle_tracking(d, s.k, pose, rp, v, n, 1e-5, (10, 5, 4))
+                    accepted += int(ok)
+                else:
+                    pose = s.pose(f).copy()
+                poses.append(pose.copy())
+                o.integrate(d, pose, s.k, mu, f)
+                ran, vv, nn = o.raycast(pose, s.k, mu, f)
+                if ran:
+                    v, n, rp = vv, nn, pose.copy()
+            o.close()
+            return np.stack(poses), accepted
+        finally:
+            lib.so_set_libm_sincos(0)
+
+    a, acc_a = loop(False)
+    b, acc_b = loop(True)
+    assert acc_a == acc_b == frames - 4
+    dt = np.abs(a[:, :3, 3] - b[:, :3, 3]).max()
+    dr = np.abs(a[:, :3, :3] - b[:, :3, :3]).max()
+    print(f"correctly rounded vs libm sinf/cosf over {frames - 4} tracked frames: translation {dt:.2e} m, rotation entry {dr:.2e}")
+    assert dt < 2e-6 and dr < 2e-7
