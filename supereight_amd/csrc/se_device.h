@@ -55,6 +55,7 @@ struct DevMap {
   float* vy;
   uint32_t* bpos;
   uint8_t* bactive;
+  uint8_t* bsat;                  // SDF: 1 = every voxel of the block has reached maxweight (its y plane no longer changes: the sweep neither reads nor writes it)
   float* nx;
   float* ny;
   uint32_t* npos;

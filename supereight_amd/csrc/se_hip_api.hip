@@ -405,6 +405,7 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemsetAsync(m.lbits, 0, p->lbits_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
+  hipMemsetAsync(m.bsat, 0, p->slots, p->stream);
   hipMemsetAsync(m.npos, 0, p->cap_nodes * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.nlevel, 0, p->cap_nodes, p->stream);
   hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
@@ -539,6 +540,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
 #endif
   ALLOC(m.bpos, cap * sizeof(uint32_t));
   ALLOC(m.bactive, (slots + 3) & ~(size_t)3);   // whole 32-bit words: se_set_active_once
+  ALLOC(m.bsat, (slots + 3) & ~(size_t)3);
   ALLOC(m.nx, capn * 8 * sizeof(float));
   ALLOC(m.ny, capn * 8 * sizeof(float));
   ALLOC(m.npos, capn * sizeof(uint32_t));
@@ -602,7 +604,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
+  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.bsat, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);

@@ -879,12 +879,20 @@ __device__ __forceinline__ void se_update_node_corner(const DevMap& m, const flo
 // SHARD: the owner-computes variant (IntegArgs::shard_world > 1) -- a template parameter because its packing code costs the
 // plain sweep 11 VGPRs (91 -> 102: 4 waves per SIMD instead of 5, 128 -> 138 us at 1024^3).
 #ifndef SE_SWEEP_WAVES
-#define SE_SWEEP_WAVES 0    // > 0: force the register budget of that many waves per SIMD (the packed form needs 98 VGPRs: 5 -> 96 + 12 B of scratch)
+#define SE_SWEEP_WAVES 5    // > 0: force the register budget of that many waves per SIMD (the packed form needs 98 VGPRs: 5 -> 96 + 12 B of scratch)
 #endif
 #if SE_SWEEP_WAVES > 0
 #define SE_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(SE_SWEEP_WAVES, SE_SWEEP_WAVES)))
 #else
 #define SE_SWEEP_OCC
+#endif
+#ifndef SE_SWEEP_SAT
+#define SE_SWEEP_SAT 0   // 1: skip the y plane of weight-saturated SDF blocks (see k_integrate).  Built on VERDICT r03's request, bit-exact
+                         // (tests/test_gpu_parity.py::test_weight_saturated_blocks_stay_bit_exact runs either way), measured, OFF: over 260 frames
+                         // the sweep is 27.6 vs 27.0 us at 512^3 and 138 vs 136 us at 1024^3 with it, and 133 vs 123 us at 1024^3 before anything
+                         // has saturated (profiles/r04j_sweep_saturation_ab.log).  A block saturates only if EVERY voxel of it keeps being
+                         // updated; voxels more than mu behind a surface never are (their weight stays 0), so every block the surface passes
+                         // through -- most of the allocated band -- never qualifies, while the flag's byte is one more dependent load per block.
 #endif
 template <bool OFUSION, bool STATS, bool SHARD>
 __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
@@ -916,6 +924,10 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     if (STATS && lane == 0) ++swept;
     float* px = m.vx + (size_t)slot * SE_BRICK_STRIDE + lane;
     float* py = m.vy + (size_t)slot * SE_BRICK_STRIDE + lane;
+    // r04, fewer bytes: once all 512 weights of an SDF block have reached maxweight, sdf_update's y <- fminf(y + 1, maxweight)
+    // (kfusion/mapping_impl.hpp:58-61) is the identity on it for good (weights never decrease, bricks are never recycled): the y
+    // plane is neither read nor written any more -- half of the block's traffic.  The flag is set by the sweep that first sees it.
+    const bool sat = !OFUSION && SE_SWEEP_SAT && __builtin_amdgcn_readfirstlane((int)m.bsat[slot]) != 0;   // (one block per wave: a scalar)
     float vx[8], vy[8];
 #ifdef SE_DIAG
     if (a.debug == 2) {
@@ -925,7 +937,11 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
 #endif
     {
 #pragma unroll
-      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
+      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = a.maxweight; }
+      if (!sat) {
+#pragma unroll
+        for (int zi = 0; zi < 8; ++zi) vy[zi] = py[zi * 64];
+      }
     }
 #ifdef SE_DIAG
     if (a.debug == 1) {
@@ -1025,13 +1041,16 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     }
     // a voxel the functor left alone is written back unchanged only if a neighbour in the same 256-byte
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
+    bool full = true;
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
 #ifdef SE_DIAG
       if (a.debug == 2) { if (vx[zi] == 12345.f) px[zi * 64] = vx[zi]; continue; }   // keep the arithmetic alive
 #endif
-      if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
+      if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; if (!sat) py[zi * 64] = vy[zi]; }
+      full = full && (vy[zi] == a.maxweight);
     }
+    if (!OFUSION && SE_SWEEP_SAT && !sat && __ballot(full) == ~0ull && lane == 0) m.bsat[slot] = 1;
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
     if (SHARD) {   // the other replicas get this block's flag and, if anything of it was in view, its voxels

@@ -131,3 +131,27 @@ def test_pipelined_stream_parity(field, W, H, N, dim, mu, frames):
     r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": v_g, "n_g": n_g}, dim / N)
     assert r["hits_gpu"] > 1000 and r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, r
     cpu.close(); gpu.close()
+
+
+@pytest.mark.parametrize("max_blocks", [0, 1 << 13], ids=["dense", "pooled"])
+def test_weight_saturated_blocks_stay_bit_exact(max_blocks):
+    """r04: once all 512 weights of an SDF block have reached maxweight (100 observations), the sweep neither reads nor writes its y
+    plane any more (k_integrate, `bsat`).  120 frames of the slow room stream -- every block in view from frame 0 saturates at
+    frame 99 -- against the oracle: maps after frames 99, 100, 101 and 119 and the raycast of the last frame, bit for bit; the run
+    must actually contain saturated blocks."""
+    W, H, N, dim, mu, frames = 160, 120, 256, 4.8, 0.1, 120
+    seen = {"sat_blocks": 0}
+
+    def on_frame(f, cpu, gpu, rec):
+        if f in (99, 100, 101, frames - 1):
+            m = compare_maps(cpu, gpu)
+            assert m["same_block_set"] and m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0, (f, m)
+            if f == frames - 1:
+                _, _, cy, _ = cpu.blocks()
+                seen["sat_blocks"] = int((cy.reshape(-1, 512) == 100.0).all(axis=1).sum())
+
+    cpu, gpu, recs = run_both(SDF, W, H, N, dim, mu, frames, max_blocks=max_blocks, on_frame=on_frame)
+    assert seen["sat_blocks"] > 100, seen
+    r = compare_raycast(recs[-1], dim / N)
+    assert r["hits_gpu"] > 1000 and r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, r
+    cpu.close(); gpu.close()
