@@ -22,6 +22,8 @@
 #include "se_track_kernels.h"
 #include "se_mesh_kernels.h"
 
+int flush_pending_raycast(se_hip_pipeline* p);   // (defined next to se_hip_frame)
+
 namespace {
 
 thread_local std::string g_err;
@@ -108,6 +110,12 @@ struct se_hip_pipeline {
   bool gate_armed = false;         // a sweep was enqueued that no scan / upload has waited for yet
   bool gate_followed = false;      // ... and a raycast was enqueued behind it
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
+  // r04, one queue for streaming callers: se_hip_frame defers a frame's raycast to the next se_hip_frame call, which launches it together with that
+  // frame's allocation scan as ONE kernel on the main stream (k_raycast_scan) -- no second queue, no wait in front of the sweep.  Any other API
+  // call launches the deferred raycast first (check()), so results are always in place when somebody looks.  SE_HIP_FUSE=0: off.
+  bool fuse = true, in_frame = false, has_pending = false;
+  float pend_pose[16] = {0}, pend_k[4] = {0}, pend_mu = 0.f;
+  uint32_t pend_frame = 0;
   bool images_complete = true; // vertex_ / normal_ hold every row of the last raycast (a row-sharded replica: only after se_hip_apply_image_tiles / se_hip_gather_images)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool scan_on_side = false;   // stream the LAST allocation scan ran on: se_hip_alloc_exchange / se_hip_alloc_commit follow it
@@ -377,9 +385,11 @@ int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
 int check(se_hip_pipeline* p) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
   int cur = -1;
-  if (hipGetDevice(&cur) == hipSuccess && cur == p->device) return SE_HIP_OK;
-  hipError_t e = hipSetDevice(p->device);
-  if (e != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  if (!(hipGetDevice(&cur) == hipSuccess && cur == p->device)) {
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  }
+  if (p->has_pending && !p->in_frame) return flush_pending_raycast(p);   // whoever calls anything but se_hip_frame gets the deferred raycast first
   return SE_HIP_OK;
 }
 
@@ -461,6 +471,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
   if (const char* ev = std::getenv("SE_HIP_OF_SCAN_TILED")) p->of_scan_tiled = std::atoi(ev) != 0;   // A/B knob
+  if (const char* ev = std::getenv("SE_HIP_FUSE")) p->fuse = std::atoi(ev) != 0;                     // A/B knob (one-queue streaming schedule)
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
 #ifdef SE_DIAG
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
@@ -598,6 +609,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
 
 int se_hip_destroy(se_hip_pipeline* p) {
   if (!p) return SE_HIP_OK;
+  p->has_pending = false;   // (a deferred raycast nobody will look at)
   hipSetDevice(p->device);
   if (p->side) hipStreamSynchronize(p->side);
   if (p->stream) hipStreamSynchronize(p->stream);
@@ -745,6 +757,39 @@ int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m) {
   return SE_HIP_OK;
 }
 
+// The deferred raycast of the previous se_hip_frame call + this frame's allocation scan as one launch on the main stream (k_raycast_scan).
+int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& sa, int scan_wgs) {
+  const DevMap& m = p->map;
+  p->has_pending = false;
+  if (int r = check_overflow(p)) return r;
+  std::memcpy(p->raycast_pose, p->pend_pose, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
+  p->images_complete = true;
+  RayLaunchArgs L = make_ray_args(p, p->pend_pose, p->pend_k, p->pend_mu);
+  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
+  const RayArgs& a = L.a;
+  const int ray_wgs = (int)L.grid.x;
+  const size_t smem = std::max(L.smem, (size_t)SE_SCAN_SLOTS * SE_WG_SCAN * sizeof(uint32_t));
+  const dim3 grid((unsigned)(ray_wgs + scan_wgs)), block(SE_WG_RAY);
+  const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
+  const size_t nb = (size_t)(m.size >> 3);
+  // (a dense grid of > 4 GiB with every level staged -- only with SE_HIP_RAY_CACHE_LEVELS raised -- takes the generic instantiation)
+  const bool shallow = !a.has_deep && !(m.dense && nb * nb * nb * (size_t)SE_BRICK_STRIDE * sizeof(float) > ((size_t)4 << 30));
+  {
+    ScopedTimer t(p, SE_HIP_K_RAYCAST);
+#define SE_RS(OF, DN, SH, O3) hipLaunchKernelGGL((k_raycast_scan<OF, DN, SH, O3>), grid, block, smem, p->stream, m, a, p->vertex, p->normal, ray_wgs, ms, p->depth, sa)
+    if (sdf) {
+      if (m.dense) { if (shallow) SE_RS(false, true, true, true); else SE_RS(false, true, false, false); }
+      else { if (shallow) SE_RS(false, false, true, false); else SE_RS(false, false, false, false); }
+    } else {
+      if (m.dense) { if (shallow) SE_RS(true, true, true, true); else SE_RS(true, true, false, false); }
+      else { if (shallow) SE_RS(true, false, true, false); else SE_RS(true, false, false, false); }
+    }
+#undef SE_RS
+  }
+  HIP_TRY(hipGetLastError());
+  return SE_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------------- integrate
 int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
   if (int r = check(p)) return r;
@@ -777,11 +822,13 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   // ... and so do handles whose key list is a caller buffer or goes into an exchange (se_hip_set_new_keys_buffer,
   // se_hip_set_exchange): whoever consumes that list is told "scan stream" by se_hip_scan_overlaps().
   const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
-  const bool ov = p->overlap && (p->sharded || caller_list || p->xgather != nullptr || hipStreamQuery(p->stream) == hipErrorNotReady);
+  // r04: a deferred raycast of the previous se_hip_frame call is waiting -> this scan rides in its launch, on the main stream (k_raycast_scan)
+  const bool fuse_now = p->has_pending && p->in_frame && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1;
+  const bool ov = !fuse_now && p->overlap && (p->sharded || caller_list || p->xgather != nullptr || hipStreamQuery(p->stream) == hipErrorNotReady);
   p->scan_on_side = ov;
   hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
-  ms.defer_occ = ov ? 1 : 0;
+  ms.defer_occ = (ov || fuse_now) ? 1 : 0;
   if (ov) { if (p->host_gate) wait_last_sweep(p); else HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0)); }
   else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here
   const bool own_list = p->map.newkeys == p->newkeys_own || p->map.newkeys == p->newkeys_own2;
@@ -798,6 +845,21 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   }
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
   const dim3 grid((npix + SE_WG_SCAN - 1) / SE_WG_SCAN), block(SE_WG_SCAN);
+  if (!sdf) {
+    // the three stages' levels (fetch_octant stops at the leaves) and their offsets in the index pyramid (tiled kernel)
+    const int dep[3] = {a.depth_fine, a.depth_mid, a.depth_coarse};
+    for (int i = 0; i < 3; ++i) { a.of_lvl[i] = std::min(dep[i], m.leaf_level); a.of_off[i] = a.of_lvl[i] >= 1 ? m.off[a.of_lvl[i]] : 0u; }
+  }
+  if (fuse_now) {
+    const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
+    const int scan_wgs = sdf ? (tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64) : (int)grid.x;
+    if (int r = launch_raycast_scan(p, ms, a, scan_wgs)) return r;
+    p->occ_commit_due = true;
+    if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
+    if (!sdf) { if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r; }
+    HIP_TRY(hipGetLastError());
+    return 1;
+  }
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
@@ -811,13 +873,9 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
         else hipLaunchKernelGGL((k_alloc_scan_sdf<false, false>), sgrid, block, 0, s, ms, p->depth, a);
       }
     } else {
-      // the three stages' levels (fetch_octant stops at the leaves) and their offsets in the index pyramid
       const int dep[3] = {a.depth_fine, a.depth_mid, a.depth_coarse};
       bool tiled = p->of_scan_tiled;
-      for (int i = 0; i < 3; ++i) {
-        a.of_lvl[i] = std::min(dep[i], m.leaf_level);
-        if (a.of_lvl[i] < 1) tiled = false; else a.of_off[i] = m.off[a.of_lvl[i]];
-      }
+      for (int i = 0; i < 3; ++i) if (a.of_lvl[i] < 1) tiled = false;
       // the tiled kernel takes "the octant is a block" as "stage 0": true for every volume the reference's step sizes produce
       // (depths max, max - 4, max - 5 against leaves at max - 3); anything else goes through the one-thread-per-pixel kernel
       tiled = tiled && dep[0] >= m.leaf_level && dep[1] < m.leaf_level && dep[2] < m.leaf_level && m.off[m.leaf_level] + ((size_t)1 << (3 * m.leaf_level)) < ((size_t)1 << 30);
@@ -1079,13 +1137,39 @@ int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4],
 
 // One frame of the hot path in one call: float_depth_ hand-over (device pointer) + integration() + raycasting().
 // The same three calls a host makes per frame, without crossing the FFI three times (ctypes: ~5 us each).
+// r04: when the handle is a plain single-device pipeline (own key lists, no row shard, no exchange, no statistics) the raycast is not launched
+// here but DEFERRED: the next se_hip_frame call launches it in one kernel with that frame's allocation scan (launch_raycast_scan), and any other
+// API call launches it first (check()), so a caller that looks at a frame's images, synchronises or tracks sees exactly what it saw before -- only a
+// caller that streams frames back to back gets the one-queue schedule.
+extern "C++" int flush_pending_raycast(se_hip_pipeline* p) {
+  if (!p->has_pending) return SE_HIP_OK;
+  p->has_pending = false;
+  const bool was = p->in_frame;
+  p->in_frame = true;      // (the nested check() must not recurse)
+  const int r = se_hip_raycast(p, p->pend_pose, p->pend_k, p->pend_mu, p->pend_frame);
+  p->in_frame = was;
+  return r < 0 ? r : SE_HIP_OK;
+}
 int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  struct InFrame { se_hip_pipeline* p; bool was; InFrame(se_hip_pipeline* q) : p(q), was(q->in_frame) { q->in_frame = true; } ~InFrame() { p->in_frame = was; } } guard(p);
   if (int r = check(p)) return r;
+  if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
+  const bool can_fuse = p->fuse && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1;
+  // a deferred raycast must run before this frame's sweep: together with this frame's scan if there is one, else on its own, now
+  if (p->has_pending && !(can_fuse && stage_runs_integration(frame, rate))) { if (int r = flush_pending_raycast(p)) return r; }
   if (device_depth_m) p->depth = device_depth_m;
   int ran = 0;
   int r = se_hip_integrate(p, pose, k, rate, mu, frame);
   if (r < 0) return r;
   ran |= r > 0 ? 1 : 0;
+  if (p->has_pending) { if (int q = flush_pending_raycast(p)) return q; }   // (cannot happen: the scan above took it along)
+  if (can_fuse && frame > 2) {     // DenseSLAMSystem.cpp:195
+    std::memcpy(p->pend_pose, pose, sizeof p->pend_pose); std::memcpy(p->pend_k, k, sizeof p->pend_k);
+    p->pend_mu = mu; p->pend_frame = frame; p->has_pending = true;
+    return ran | 2;
+  }
   r = se_hip_raycast(p, pose, k, mu, frame);
   if (r < 0) return r;
   ran |= r > 0 ? 2 : 0;

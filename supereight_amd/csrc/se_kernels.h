@@ -32,6 +32,9 @@
                         // every lane of a wave in which any lane is in that state, and half of them are fetched past the end of the walk.
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
+#ifndef SE_COST_BATCH
+#define SE_COST_BATCH 5   // raycast scheduling: cost of a tile = trips of its slowest ray + SE_COST_BATCH * its march batches (fitted against per-wave clocks in r02)
+#endif
 #ifndef SE_FIRST_LEAF_LITE
 #define SE_FIRST_LEAF_LITE 1   // raycast: stack-free first-leaf search (se_first_leaf_lite); 0 = the iterator with its LDS stack for every ray
 #endif
@@ -187,9 +190,10 @@ __device__ __forceinline__ int se_cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f
 #ifndef SE_SCAN_INT
 #define SE_SCAN_INT 1   // 1: block coordinates through v_cvt_flr_i32_f32 and one range test on the OR of the three integers (see below)
 #endif
+// (the body of the kernel, so that k_raycast_scan can run it as part of a raycast launch: `bid` = workgroup index within the scan's grid,
+// s_blk_all = SE_SCAN_SLOTS * SE_WG_SCAN words of LDS)
 template <bool STATS, bool DENSE>
-__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
-  __shared__ uint32_t s_blk_all[SE_SCAN_SLOTS * SE_WG_SCAN];
+__device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __restrict__ depthmap, const AllocArgs& a, uint32_t* s_blk_all, int bid) {
   uint32_t* s_blk = s_blk_all + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
   int x, y;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
   {
     // a wave scans an 8x8 pixel tile: its rays cross the same 1-2 blocks per step (64 pixels of a row measured the same)
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
+    const int tile = bid * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
     const int tiles_x = (a.W + 7) >> 3;
     x = (tile % tiles_x) * 8 + (lane & 7);
     y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
@@ -264,6 +268,11 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
   se_stat_add<STATS>(m, S_PROBES, probes);
   se_stat_add<STATS>(m, S_NEWKEYS, newk);
 }
+template <bool STATS, bool DENSE>
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+  __shared__ uint32_t s_blk_all[SE_SCAN_SLOTS * SE_WG_SCAN];
+  se_scan_sdf_wg<STATS, DENSE>(m, depthmap, a, s_blk_all, (int)blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------
 // OFusion allocation scan: buildOctantList (se_denseslam/src/bfusion/alloc_impl.hpp:56-129)
@@ -271,9 +280,9 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
 // three-stage step size; coarse steps insert childless octants at levels leaf-1 / leaf-2.
 // ------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+__device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float* __restrict__ depthmap, const AllocArgs& a, int bid) {
   const int npix = (a.row_end - a.row_begin) * a.W;
-  const int pid = blockIdx.x * SE_WG_SCAN + threadIdx.x;
+  const int pid = bid * SE_WG_SCAN + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
   if (pid < npix) {
     const int x = pid % a.W;
@@ -322,6 +331,10 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, con
   }
   se_stat_add<STATS>(m, S_PROBES, probes);
   se_stat_add<STATS>(m, S_NEWKEYS, newk);
+}
+template <bool STATS>
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+  se_scan_ofusion_wg<STATS>(m, depthmap, a, (int)blockIdx.x);
 }
 
 // r04, built on VERDICT r03's request, measured, OFF by default (SE_HIP_OF_SCAN_TILED=1): the same scan with the SDF scan's structure.
@@ -2270,14 +2283,14 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 #else
 #define SE_RAY_OCC
 #endif
-template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW, bool O32 = false>   // O32: the voxel planes span <= 4 GiB (dense 512^3): 32-bit byte offsets
-__global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
+// The kernel's body (k_raycast_scan runs it for the first workgroups of a fused launch): `bid` = workgroup index within the raycast's grid.
+template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW, bool O32>   // O32: the voxel planes span <= 4 GiB (dense 512^3): 32-bit byte offsets
+__device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a, float* __restrict__ vertex, float* __restrict__ normal, uint32_t* smem, const int bid) {
   // LDS: [occupancy words of levels 1..cache_levels][ray stack: parent codes][ray stack: t_max]
-  extern __shared__ uint32_t smem[];
   uint32_t* s_occ = smem;
   uint32_t* s_par = smem + a.cache_words;
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
-  if (a.gate && blockIdx.x == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
+  if (a.gate && bid == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifdef SE_DIAG
   const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
@@ -2298,7 +2311,7 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
   const int n_tiles = tiles_x * tiles_y, n_pairs = (n_tiles + 1) >> 1;
   int tile;
   {
-    const int rnd = blockIdx.x / a.n_cus, cu = blockIdx.x - rnd * a.n_cus;
+    const int rnd = bid / a.n_cus, cu = bid - rnd * a.n_cus;
     const int pos = rnd * a.n_cus + ((rnd & 1) ? a.n_cus - 1 - cu : cu);
     const int pair = pos < n_pairs ? (int)a.ray_order[pos] : n_pairs;   // (positions of the last, partial round beyond the list: no pair)
     tile = 2 * pair + (threadIdx.x >> 6);
@@ -2351,7 +2364,7 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
       RayCounters rc = {0ull, 0ull, 0u};
       se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
       if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
-      my_cost = 5u * rc.n_batch;
+      my_cost = (unsigned)SE_COST_BATCH * rc.n_batch;
 #ifdef SE_DIAG
       if (STATS) d_batches = rc.n_batch;
 #endif
@@ -2429,6 +2442,29 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
     }
 #endif
   }
+}
+
+template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW, bool O32 = false>
+__global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal) {
+  extern __shared__ uint32_t smem[];
+  se_raycast_wg<OFUSION, STATS, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, (int)blockIdx.x);
+}
+// r04: raycast of frame f and allocation scan of frame f+1 in ONE launch on ONE queue.  The two always ran side by side (the scan on a second
+// queue behind a host gate), and the price of the second queue was the wait in front of the next sweep: 5.3 us of a 67 us frame for an event that
+// has long fired when the queue reaches it.  Here the first `ray_wgs` workgroups are the raycast's, the rest the scan's: they share the
+// chip exactly as before -- the raycast's workgroups are dispatched first, the scan's fill in as those retire -- and sweep(f) -> [raycast(f), scan(f+1)]
+// -> sweep(f+1) are consecutive launches of one queue with nothing between them.  The scan defers its occupancy bits (the raycast reads occ[]), the
+// sweep behind publishes them, as in the two-queue schedule.  Needs both frames' inputs at launch time: se_hip_frame defers a frame's raycast to the
+// next call (any other API call flushes it first), so only a caller that streams frames without looking at each result gets this path.
+static_assert(SE_WG_RAY == SE_WG_SCAN, "the fused raycast + scan launch uses one workgroup size");
+template <bool OFUSION, bool DENSE, bool SHALLOW, bool O32>
+__global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast_scan(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal, int ray_wgs,
+                                                                         DevMap ms, const float* __restrict__ depthmap, AllocArgs sa) {
+  extern __shared__ uint32_t smem[];
+  if ((int)blockIdx.x < ray_wgs) { se_raycast_wg<OFUSION, false, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, (int)blockIdx.x); return; }
+  const int bid = (int)blockIdx.x - ray_wgs;
+  if (OFUSION) se_scan_ofusion_wg<false>(ms, depthmap, sa, bid);
+  else se_scan_sdf_wg<false, DENSE>(ms, depthmap, sa, smem, bid);   // (its SE_SCAN_SLOTS * SE_WG_SCAN words fit the raycast's LDS allocation: checked by the host)
 }
 
 // map read-back: packs the bricks named by slots[] (already in the caller's order) contiguously

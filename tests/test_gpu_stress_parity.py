@@ -102,7 +102,10 @@ def test_stress_stream_pipelined(field, mu, frames, max_blocks):
         assert gpu.image_tile_bytes(H) == ring[0].numel() * 4
         for f in range(frames):
             gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)
-            if f > 2:
+            # r04: se_hip_frame defers the raycast to the next frame call, which launches it in one kernel with that frame's scan
+            # (k_raycast_scan); any other call -- this copy -- launches it first.  Every third frame is copied, so the stream mixes
+            # fused launches (two of three frames) with stand-alone raycasts beside a side-stream scan
+            if f > 2 and (f % 3 == 0 or f == frames - 1):
                 gpu.pack_image_tile(ring[f].data_ptr(), H)     # device-to-device on the pipeline's main stream, behind this frame's raycast
         gpu.sync()
         return gpu, ring.cpu().numpy()
@@ -114,13 +117,13 @@ def test_stress_stream_pipelined(field, mu, frames, max_blocks):
     for f in range(frames):
         cpu.integrate(depths[f], poses[f], s.k, mu, f)
         ran, v_c, n_c = cpu.raycast(poses[f], s.k, mu, f)
-        if ran:
+        if ran and (f % 3 == 0 or f == frames - 1):
             r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": ring[f, 0], "n_g": ring[f, 1]}, dim / N)
             hits += r["hits_gpu"]
             for kk in worst:
                 worst[kk] = max(worst[kk], r[kk])
             assert r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, (f, r)
-    assert hits > 1000 * (frames - 3), hits
+    assert hits > 300 * (frames - 3), hits
     m = compare_maps(cpu, gpu)
     assert m["same_block_set"] and m["same_node_set"], m
     assert m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0, m
