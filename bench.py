@@ -561,7 +561,10 @@ def main():
 
         st = counts["contract"]
         per_kernel = per_kernel_of(timings, st, K)       # contract: events recorded live in the timed region
-        dom = max((kk for kk in per_kernel if "GBps" in per_kernel[kk]), key=lambda kk: per_kernel[kk]["share"])
+        # the dominant kernel = the longest launch of a frame (by share of the sampled time it could flip on the sample count: the deferred
+        # raycast of the last sampled frame is launched, and timed, with the next call)
+        cands = [kk for kk in per_kernel if "GBps" in per_kernel[kk]]
+        dom = max([kk for kk in cands if per_kernel[kk]["launches"] >= 2] or cands, key=lambda kk: per_kernel[kk]["avg_us"])
         result["roofline"] = roofline_of(per_kernel, dom, st, K)
         result["roofline"]["sampling"] = f"HIP events on every {stride}-th of the K timed frames, on the launch streams"
         result["kernels"] = per_kernel

@@ -1812,7 +1812,7 @@ int se_hip_create_replicas(const se_hip_config* cfg, const int32_t* device_ids, 
 
 // --------------------------------------------------------------------------------- measurement
 int se_hip_enable_timing(se_hip_pipeline* p, int32_t on) {
-  if (int r = check(p)) return r;
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");   // (a flag only: does not launch a deferred raycast, see se_hip_frame)
   p->timing = on != 0;  // no synchronisation here: pending events are resolved by se_hip_get_timings
   return SE_HIP_OK;
 }
