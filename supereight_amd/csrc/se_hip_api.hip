@@ -770,13 +770,14 @@ int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& s
   const int ray_wgs = (int)L.grid.x;
   const size_t smem = std::max(L.smem, (size_t)SE_SCAN_SLOTS * SE_WG_SCAN * sizeof(uint32_t));
   const dim3 grid((unsigned)(ray_wgs + scan_wgs)), block(SE_WG_RAY);
+  const int first_round = 10 * p->n_cus;   // workgroups of 2 waves the chip holds at once at 5 waves per SIMD (k_raycast_scan)
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   const size_t nb = (size_t)(m.size >> 3);
   // (a dense grid of > 4 GiB with every level staged -- only with SE_HIP_RAY_CACHE_LEVELS raised -- takes the generic instantiation)
   const bool shallow = !a.has_deep && !(m.dense && nb * nb * nb * (size_t)SE_BRICK_STRIDE * sizeof(float) > ((size_t)4 << 30));
   {
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
-#define SE_RS(OF, DN, SH, O3) hipLaunchKernelGGL((k_raycast_scan<OF, DN, SH, O3>), grid, block, smem, p->stream, m, a, p->vertex, p->normal, ray_wgs, ms, p->depth, sa)
+#define SE_RS(OF, DN, SH, O3) hipLaunchKernelGGL((k_raycast_scan<OF, DN, SH, O3>), grid, block, smem, p->stream, m, a, p->vertex, p->normal, ray_wgs, ms, p->depth, sa, scan_wgs, first_round)
     if (sdf) {
       if (m.dense) { if (shallow) SE_RS(false, true, true, true); else SE_RS(false, true, false, false); }
       else { if (shallow) SE_RS(false, false, true, false); else SE_RS(false, false, false, false); }
@@ -1156,7 +1157,11 @@ int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float po
   if (int r = check(p)) return r;
   if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
-  const bool can_fuse = p->fuse && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1;
+  // ... and only while the raycast's workgroups fit the chip in one round (640x480: 2 400 of 2 560): in a launch of several rounds the scan's workgroups
+  // inherit the raycast's register and LDS footprint and no longer slip into the gaps -- 1280x960 -> 2048^3: 356 us fused against 285 us side by side,
+  // 841 vs 883 frames/s (profiles/r04p_march_skip_ab.log) -- so larger images keep the two-queue schedule
+  const int ray_pairs = (((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H) + 1) / 2;
+  const bool can_fuse = p->fuse && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
   // a deferred raycast must run before this frame's sweep: together with this frame's scan if there is one, else on its own, now
   if (p->has_pending && !(can_fuse && stage_runs_integration(frame, rate))) { if (int r = flush_pending_raycast(p)) return r; }
   if (device_depth_m) p->depth = device_depth_m;

@@ -1714,6 +1714,10 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 #ifndef SE_MARCH_LEAN
 #define SE_MARCH_LEAN 1
 #endif
+#ifndef SE_MARCH_SKIP
+#define SE_MARCH_SKIP 4    // SDF march in unobserved space: positions asked of the leaf bitmap per round trip (se_march_skip); 0 = off.  Measured 0 / 4 / 8
+                           // (profiles/r04p_march_skip_ab.log): 59.8 / 59.8 / 61.6 us per frame at 512^3, 193.8 / 188.4 / 189.5 at 1024^3, stress 69.7 / 68.6 / 71.3
+#endif
 #ifndef SE_MARCH_PROBE
 #define SE_MARCH_PROBE 1   // dense maps > 512^3: leaf-bitmap probe in front of brick reads while the march is in unobserved space (se_cast_ray_sdf_lean)
 #endif
@@ -1804,6 +1808,47 @@ __device__ __forceinline__ f3 se_grad_lean(const DevMap& m, const FieldConst fc,
          ((V[3][2][1] - V[1][2][1]) * (1 - fx) + (V[3][2][2] - V[1][2][2]) * fx) * fy) * fz;
   return g;
 }
+// Walking through unobserved space (r04).  While the last value had weight 0 the reference's march takes `largestep` after `largestep` until a get()
+// returns a weight again; 43 % of all samples of a frame are such steps, most of them in blocks that were never allocated, and each pair of them
+// was a dependent memory round trip.  The next SE_MARCH_SKIP positions -- formed by the same float additions the loop performs -- are asked of the
+// leaf bitmap together (L2-resident; outside the volume and "no block here" both read as initValue(), weight 0), and the leading ones that have no
+// block are consumed exactly as the loop would consume them (t < tfar tested before each, t += largestep after), without touching a brick or the index.
+// The first position that has a block ends the run; the regular batch takes over there.  Results cannot change: an absent block's voxels ARE
+// initValue() (dense: pre-filled bricks; pooled: no brick), also while the next frame's scan is inserting blocks beside this launch (a fresh brick
+// holds initValue() too).  Returns true if the march is over (t reached tfar).
+template <bool STATS>
+__device__ __forceinline__ bool se_march_skip(const DevMap& m, const RayArgs& a, f3 dir, float tfar, f3& position, float& t, RayCounters& rc) {
+#if SE_MARCH_SKIP > 0
+  const f3 sd = f3_scale(a.largestep, dir);
+  f3 q[SE_MARCH_SKIP];
+  uint32_t lin[SE_MARCH_SKIP], w[SE_MARCH_SKIP];
+  bool in[SE_MARCH_SKIP];
+  q[0] = position;
+#pragma unroll
+  for (int i = 1; i < SE_MARCH_SKIP; ++i) q[i] = f3_add(q[i - 1], sd);
+#pragma unroll
+  for (int i = 0; i < SE_MARCH_SKIP; ++i) {
+    const int ix = se_cvt_hw(a.inv_voxel * q[i].x), iy = se_cvt_hw(a.inv_voxel * q[i].y), iz = se_cvt_hw(a.inv_voxel * q[i].z);
+    in[i] = (uint32_t)(ix | iy | iz) < (uint32_t)m.size;
+    lin[i] = in[i] ? block_linear(m, ix >> 3, iy >> 3, iz >> 3) : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < SE_MARCH_SKIP; ++i) w[i] = m.lbits[lin[i] >> 5];
+  bool run = true;
+#pragma unroll
+  for (int i = 0; i < SE_MARCH_SKIP; ++i) {
+    const bool present = in[i] && ((w[i] >> (lin[i] & 31u)) & 1u);
+    run = run && !present;
+    if (run) {
+      if (!(t < tfar)) return true;
+      if (STATS) ++rc.n_get;
+      position = f3_add(position, sd);
+      t += a.largestep;
+    }
+  }
+#endif
+  return false;
+}
 // one get(): voxel coordinates, inside-the-volume flag and index of the sample at q (metres)
 template <bool O32> struct SeSample { typename SeDense<O32>::idx_t vi; bool in; };
 template <bool O32>
@@ -1836,6 +1881,10 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
   bool unobs = false;      // the last consumed sample had weight 0 (unobserved space)
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
+    if (SE_MARCH_SKIP > 0 && unobs) {   // (S == stepsize == largestep in this state)
+      if (se_march_skip<STATS>(m, a, dir, tfar, position, t, rc)) break;
+      if (!(t < tfar)) break;
+    }
     const f3 q0 = position;
     const f3 q1 = f3_add(q0, f3_scale(S, dir));
     SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
@@ -1952,6 +2001,10 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
   SePCache pc = {0xFFFFFFFFu, 0u};
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
+    if (SE_MARCH_SKIP > 0 && unobs) {
+      if (se_march_skip<STATS>(m, a, dir, tfar, position, t, rc)) break;
+      if (!(t < tfar)) break;
+    }
     const f3 q0 = position;
     const f3 q1 = f3_add(q0, f3_scale(S, dir));
     const SePSample s0 = se_sample_pooled<true>(m, a, q0, pc, unobs), s1 = se_sample_pooled<true>(m, a, q1, pc, unobs);
@@ -2459,10 +2512,22 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
 static_assert(SE_WG_RAY == SE_WG_SCAN, "the fused raycast + scan launch uses one workgroup size");
 template <bool OFUSION, bool DENSE, bool SHALLOW, bool O32>
 __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast_scan(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal, int ray_wgs,
-                                                                         DevMap ms, const float* __restrict__ depthmap, AllocArgs sa) {
+                                                                         DevMap ms, const float* __restrict__ depthmap, AllocArgs sa, int scan_wgs, int first_round) {
   extern __shared__ uint32_t smem[];
-  if ((int)blockIdx.x < ray_wgs) { se_raycast_wg<OFUSION, false, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, (int)blockIdx.x); return; }
-  const int bid = (int)blockIdx.x - ray_wgs;
+  // Dispatch order = blockIdx order.  The first `first_round` workgroups (what the chip holds at once) are the raycast's; behind them raycast and
+  // scan workgroups alternate until one kind runs out.  With all scan workgroups at the very end (the first version) a launch of several rounds --
+  // 1280x960: four -- only started scanning when its last raycast round was dispatched: 362 us at 2048^3 for a 195 us raycast and a 160 us scan.
+  int bid, is_scan;
+  {
+    const int b = (int)blockIdx.x, F = min(first_round, ray_wgs), I = min(ray_wgs - F, scan_wgs);
+    if (b < F) { is_scan = 0; bid = b; }
+    else {
+      const int j = b - F;
+      if (j < 2 * I) { is_scan = j & 1; bid = is_scan ? (j >> 1) : F + (j >> 1); }
+      else { const int k = j - 2 * I; is_scan = (ray_wgs - F > I) ? 0 : 1; bid = is_scan ? I + k : F + I + k; }
+    }
+  }
+  if (!is_scan) { se_raycast_wg<OFUSION, false, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, bid); return; }
   if (OFUSION) se_scan_ofusion_wg<false>(ms, depthmap, sa, bid);
   else se_scan_sdf_wg<false, DENSE>(ms, depthmap, sa, smem, bid);   // (its SE_SCAN_SLOTS * SE_WG_SCAN words fit the raycast's LDS allocation: checked by the host)
 }
