@@ -455,6 +455,7 @@ def main():
         t3 = time.perf_counter()
         sustained = {"frames": K + extra, "fps": (K + extra) / (elapsed + (t3 - t2)), "fps_second_region": extra / (t3 - t2),
                      "note": f"the K = {K} contract steps plus {extra} more frames of the same stream, two timed regions added up"}
+    fused_schedule = world == 1 and sp.p.frame_is_fused()
     timings = sp.p.timings(reset=True) if not args.no_events else None
     sp.p.enable_timing(False)
     nblocks, nnodes = sp.p.counts()
@@ -474,6 +475,8 @@ def main():
             "config": {"workload": f"{stream_name} {W}x{H} -> {N}^3 / {dim} m "
                                    f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
                                    f"GT poses, frames {warm}..{warm + K - 1} timed",
+                       "schedule": ("one queue: raycast(f) + scan(f+1) in one launch, sweep(f+1) behind it (se_hip_frame defers the raycast to the next call)" if fused_schedule
+                                    else "two queues: scan(f+1) on a side stream beside raycast(f), event wait in front of sweep(f+1)"),
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists" + (", sweep sharded by block owner + RCCL all-gather of the updated bricks" if sp.shard_sweep else ""),
                        "blocks_allocated": nblocks, "nodes_allocated": nnodes,
                        "prewarm": f"{prewarm_frames} untimed frames on a scratch map before the W warm-up frames (clocks / caches warm, see bench.py prewarm()); "
@@ -494,6 +497,7 @@ def main():
     if rank == 0 and timings is not None and world == 1:
         voxel_bytes = 8 if field == SDF else 16     # the reference layout; the device stores 8 B per voxel for both field types
         windows = [("contract", warm, warm + K)] + ([("sustained", warm, F)] if extra else [])
+        fused = fused_schedule
         # (1) instrumented replay of the same frames: exact work counts of the launches of each window
         rp = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=local_rank)
         rp.enable_stats(True)
@@ -529,6 +533,8 @@ def main():
 
         def per_kernel_of(tm, st, frames):
             ab = algorithmic_bytes(st, frames, W, H, voxel_bytes)
+            if fused:   # one launch does the raycast of frame f AND the allocation scan of frame f+1 (k_raycast_scan): its units are both
+                ab["raycast"] = ab["raycast"] + ab["alloc_scan"]
             out = {}
             for kk, v in tm.items():
                 if v["launches"] == 0:
@@ -567,6 +573,9 @@ def main():
         dom = max([kk for kk in cands if per_kernel[kk]["launches"] >= 2] or cands, key=lambda kk: per_kernel[kk]["avg_us"])
         result["roofline"] = roofline_of(per_kernel, dom, st, K)
         result["roofline"]["sampling"] = f"HIP events on every {stride}-th of the K timed frames, on the launch streams"
+        if fused:
+            result["roofline"]["launch"] = ("k_raycast_scan: the raycast of frame f and the allocation scan of frame f+1 are ONE launch (one-queue streaming schedule, "
+                                            "se_hip_frame); algorithmic bytes = A_ray + A_alloc of SURVEY 8(d), duration = that launch's")
         result["kernels"] = per_kernel
         result["work_per_frame"] = {kk: st[kk] / K for kk in ("probes", "new_keys", "swept", "gets", "interps", "grads", "hits")}
         # the same figure from the every-frame replay, for the contract window and for the sustained window

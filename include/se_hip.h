@@ -94,6 +94,11 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
  * stream is idle at the call (a caller that synchronises every frame) gets the scan straight onto the main stream, and
  * nobody else consumes its list.  se_hip_alloc_exchange / se_hip_alloc_commit follow the stream the last scan ran on. */
 int se_hip_scan_overlaps(se_hip_pipeline* p);
+/* 1 if se_hip_frame runs the one-queue streaming schedule on this handle (r04): the raycast of a frame is deferred to the next se_hip_frame call,
+ * which launches it together with that frame's allocation scan as one kernel on the main stream; any other entry point launches a deferred raycast
+ * first, so nothing a caller can read is ever stale.  Plain single-device handles with images of up to 2 560 raycast workgroups (640x480) only;
+ * SE_HIP_FUSE=0 switches it off.  Does not itself launch the deferred raycast. */
+int se_hip_frame_is_fused(se_hip_pipeline* p);
 
 /* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by
  * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141). */
@@ -172,7 +177,11 @@ int se_hip_gather_images(se_hip_pipeline* p, void* send_device, void* recv_devic
 
 /* One frame of the loop of se_apps/src/benchmark.cpp:148-167 in one call: hand-over of a device-resident float_depth_
  * (NULL = keep the current depth image), then integration(), then raycasting() with the same pose -- exactly
- * se_hip_set_depth_device + se_hip_integrate + se_hip_raycast.  Returns bit 0 = integration ran, bit 1 = raycasting ran. */
+ * se_hip_set_depth_device + se_hip_integrate + se_hip_raycast.  Returns bit 0 = integration ran, bit 1 = raycasting ran.
+ * r04: on a handle for which se_hip_frame_is_fused() is 1 the raycast is ENQUEUED LATER -- together with the next se_hip_frame call's allocation scan,
+ * as one kernel -- or by the next call of any other entry point of this header (se_hip_sync, the image getters, se_hip_track, ...), whichever
+ * comes first; what a caller can observe is unchanged.  The depth image handed over must stay valid until the next call (it always had to:
+ * the scan reads it asynchronously). */
 int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t integration_rate,
                  float mu, uint32_t frame);
 

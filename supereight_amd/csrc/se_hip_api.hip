@@ -1142,6 +1142,15 @@ int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4],
 // here but DEFERRED: the next se_hip_frame call launches it in one kernel with that frame's allocation scan (launch_raycast_scan), and any other
 // API call launches it first (check()), so a caller that looks at a frame's images, synchronises or tracks sees exactly what it saw before -- only a
 // caller that streams frames back to back gets the one-queue schedule.
+static bool frame_can_fuse(se_hip_pipeline* p) {
+  const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
+  const int ray_pairs = (((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H) + 1) / 2;
+  return p->fuse && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
+}
+int se_hip_frame_is_fused(se_hip_pipeline* p) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  return frame_can_fuse(p) ? 1 : 0;
+}
 extern "C++" int flush_pending_raycast(se_hip_pipeline* p) {
   if (!p->has_pending) return SE_HIP_OK;
   p->has_pending = false;
@@ -1156,12 +1165,10 @@ int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float po
   struct InFrame { se_hip_pipeline* p; bool was; InFrame(se_hip_pipeline* q) : p(q), was(q->in_frame) { q->in_frame = true; } ~InFrame() { p->in_frame = was; } } guard(p);
   if (int r = check(p)) return r;
   if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
-  const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
-  // ... and only while the raycast's workgroups fit the chip in one round (640x480: 2 400 of 2 560): in a launch of several rounds the scan's workgroups
+  // (only while the raycast's workgroups fit the chip in one round -- 640x480: 2 400 of 2 560 --: in a launch of several rounds the scan's workgroups
   // inherit the raycast's register and LDS footprint and no longer slip into the gaps -- 1280x960 -> 2048^3: 356 us fused against 285 us side by side,
-  // 841 vs 883 frames/s (profiles/r04p_march_skip_ab.log) -- so larger images keep the two-queue schedule
-  const int ray_pairs = (((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H) + 1) / 2;
-  const bool can_fuse = p->fuse && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
+  // 841 vs 883 frames/s (profiles/r04p_march_skip_ab.log) -- so larger images keep the two-queue schedule)
+  const bool can_fuse = frame_can_fuse(p);
   // a deferred raycast must run before this frame's sweep: together with this frame's scan if there is one, else on its own, now
   if (p->has_pending && !(can_fuse && stage_runs_integration(frame, rate))) { if (int r = flush_pending_raycast(p)) return r; }
   if (device_depth_m) p->depth = device_depth_m;

@@ -44,6 +44,7 @@ EXPORTS = {
     "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_scan_overlaps": (C.c_int, [C.c_void_p]),
+    "se_hip_frame_is_fused": (C.c_int, [C.c_void_p]),
     "se_hip_upload_depth": (C.c_int, [C.c_void_p, _f32p]),
     "se_hip_upload_depth_mm": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     "se_hip_set_depth_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -203,6 +204,10 @@ class DenseSLAMPipeline:
 
     def scan_overlaps(self) -> bool:
         return bool(self._check(self.lib.se_hip_scan_overlaps(self._h)))
+
+    def frame_is_fused(self) -> bool:
+        """True if frame() runs the one-queue streaming schedule (deferred raycast + next frame's scan in one launch, include/se_hip.h)."""
+        return bool(self._check(self.lib.se_hip_frame_is_fused(self._h)))
 
     def set_scan_stream(self, hip_stream_ptr: int):
         self._check(self.lib.se_hip_set_scan_stream(self._h, C.c_void_p(hip_stream_ptr)))
