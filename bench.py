@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--sustain", type=int, default=200, help="N = 1: after the K contract steps keep going until this many frames have been timed in total (0 = off)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU warm-up on a scratch map before the warm-up frames (see prewarm())")
     ap.add_argument("--shard-sweep", action="store_true", help="N > 1: owner-computes integration + brick all-gather instead of the replicated sweep (SURVEY 8e option 4; DESIGN.md section 7: measured slower, off by default)")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the value_closed_loop leg (profiling runs: nothing behind the timed loop)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra N = 1 legs (closed loop, tracking on, pooled bricks)")
     ap.add_argument("--mode-frames", type=int, default=60, help="timed frames of each extra leg")
     ap.add_argument("--config4", action="store_true", help="also run BASELINE configs[3] (1280x960 -> 2048^3) with the same rank layout and print it beside the contract line (default on for N > 1)")
@@ -569,8 +570,10 @@ def main():
         per_kernel = per_kernel_of(timings, st, K)       # contract: events recorded live in the timed region
         # the dominant kernel = the longest launch of a frame (by share of the sampled time it could flip on the sample count: the deferred
         # raycast of the last sampled frame is launched, and timed, with the next call)
-        cands = [kk for kk in per_kernel if "GBps" in per_kernel[kk]]
-        dom = max([kk for kk in cands if per_kernel[kk]["launches"] >= 2] or cands, key=lambda kk: per_kernel[kk]["avg_us"])
+        # ... judged on the every-launch replay where there is one (the live sample is K / stride launches: one slow launch of ten moved it)
+        judge = per_kernel_of(replay["contract"], st, K) if "contract" in replay else per_kernel
+        cands = [kk for kk in per_kernel if "GBps" in per_kernel[kk] and kk in judge]
+        dom = max([kk for kk in cands if judge[kk]["launches"] >= 2] or cands, key=lambda kk: judge[kk]["avg_us"])
         result["roofline"] = roofline_of(per_kernel, dom, st, K)
         result["roofline"]["sampling"] = f"HIP events on every {stride}-th of the K timed frames, on the launch streams"
         if fused:
@@ -639,7 +642,7 @@ def main():
                                             "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists"}}
         del dev4
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_closed_loop:
         # SURVEY 8(d)'s own bracketing (se_apps/src/benchmark.cpp:148-167: wall clock around integration() + raycasting()
         # including the device sync, frame by frame): the SAME K frames as `value`, a fresh map, one se_hip_sync() per frame,
         # nothing of frame f+1 issued before frame f has finished.  This is the figure a SLAM loop whose next pose depends

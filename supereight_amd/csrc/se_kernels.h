@@ -1036,7 +1036,9 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
       const float pixy = camera_voxel.y * inverse_depth + 0.5f;
       valid[zi] = !(pos[zi].z < 0.0001f) && !(pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f);
       visible = visible || valid[zi];
-      pidx[zi] = valid[zi] ? cvt_i32(pixx) + a.W * cvt_i32(pixy) : 0;   // sdf_update / bfusion_update: pixel.cast<int>()
+      // sdf_update / bfusion_update: pixel.cast<int>().  A valid pixel lies in [0.5, W - 1.5] x [0.5, H - 1.5], where the hardware conversion (one
+      // instruction) equals the x86 cast; an invalid one reads pixel 0 and is discarded (NaN cannot be valid: it needs camera_voxel.z == 0 == pos.z)
+      pidx[zi] = valid[zi] ? se_cvt_hw(pixx) + a.W * se_cvt_hw(pixy) : 0;
     }
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) ds[zi] = depthmap[pidx[zi]];
@@ -1721,7 +1723,6 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 #ifndef SE_MARCH_PROBE
 #define SE_MARCH_PROBE 1   // dense maps > 512^3: leaf-bitmap probe in front of brick reads while the march is in unobserved space (se_cast_ray_sdf_lean)
 #endif
-__device__ __forceinline__ int se_cvt_hw(float f) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
 template <bool O32> struct SeDense;
 template <> struct SeDense<true> {     // byte-offset terms, 32 bit
   typedef uint32_t idx_t;

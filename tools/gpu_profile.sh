@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 export SE_PROF_LAST=${SE_PROF_LAST:-50}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps $SE_PROF_LAST --warmup 10 --no-events --no-cpu-baseline --no-modes --sustain 0 $@"
+BENCH="python bench.py --steps $SE_PROF_LAST --warmup 10 --no-events --no-cpu-baseline --no-modes --no-closed-loop --sustain 0 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 if [ "$WHAT" != sq ]; then
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err

@@ -86,15 +86,17 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_cache", "pmc_tlb", "pmc_lat
 import json
 fetch, write = {}, {}
 nlaunch = {}
+last_seen = {}
 for sub, dst in (("pmc_fetch", fetch), ("pmc_write", write)):
     files = find(sub, "*counter_collection.csv")
     if not files:
         continue
     acc = defaultdict(list)
     with open(files[0]) as fh:
-        for row in csv.DictReader(fh):
+        for n_row, row in enumerate(csv.DictReader(fh)):
             if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+                last_seen[short(row["Kernel_Name"])] = n_row
     for k, v in acc.items():
         nlaunch[k] = max(nlaunch.get(k, 0), len(v))
         v = v[-LAST:]
@@ -103,7 +105,11 @@ names = {"k_alloc_scan": "alloc_scan", "k_integrate": "integrate", "k_raycast": 
 kern = {}
 # several kernels can share a prefix (r04: k_raycast_scan = raycast + the next frame's scan in one launch, beside a few stand-alone
 # k_raycast launches of the warm-up frames): the one with the most launches is the frame loop's
-for k in sorted(fetch, key=lambda kk: nlaunch.get(kk, 0)):
+# ... or rather: the one still being launched when the run ends (rows are in dispatch order; the timed loop comes last, the pre-warm's hundreds of
+# stand-alone k_raycast launches first), provided it has the timed region's worth of launches
+# (bench.py's closed-loop leg runs behind the timed loop and launches stand-alone k_raycast again: where the fused k_raycast_scan has the timed
+# region's launches it IS the timed loop's raycast launch, whatever comes later; tools/gpu_profile.sh now passes --no-closed-loop)
+for k in sorted(fetch, key=lambda kk: (nlaunch.get(kk, 0) >= LAST, kk.startswith("k_raycast_scan"), last_seen.get(kk, 0))):
     for pre, nice in names.items():
         if k.startswith(pre) and k in write:
             kern[nice] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k],
