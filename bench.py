@@ -235,8 +235,9 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
       closed_loop  integration() + raycasting() + se_hip_sync() per frame -- the reference's own bracketing
                    (se_apps/src/benchmark.cpp:148-167): nothing of frame f+1 is issued before frame f has finished,
                    i.e. what a SLAM loop whose next pose depends on this raycast can use;
-      tracking_on  the full loop tracking() -> integration() -> raycasting() with the ICP-tracked pose (GT pose for
-                   frames 0..3 only); tracking synchronises with the host once per ICP iteration;
+      tracking_on  the full loop tracking() -> integration() (if tracked) -> raycasting() with the ICP-tracked pose (GT pose
+                   for frames 0..3 only), one se_hip_frame_tracked call + one se_hip_sync per frame; the ICP loop runs on the
+                   device and hands the host one record per frame;
       pooled       the headline's pipelined loop on pooled bricks (max_blocks set: bump-allocated bricks behind the
                    index instead of one brick slot per grid cell)."""
     from supereight_amd.pipeline import DenseSLAMPipeline
@@ -256,13 +257,13 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
                 p.sync()
                 t0 = time.perf_counter()
             if track:
-                p.set_depth_device(depth_ptrs[f])
-                if f > 3:
-                    tracked += int(p.tracking(k, 1e-5, 1, f))
+                if f > 3:       # tracking(); if tracked: integration(); raycasting() -- benchmark.cpp:115-150 -- in one FFI call
+                    tracked += (p.frame_tracked(depth_ptrs[f], k32, mu, f) >> 2) & 1
                 else:
                     p.setPose(poses[f])
-                p.integration(k, 1, mu, f)
-                p.raycasting(k, mu, f)
+                    p.set_depth_device(depth_ptrs[f])
+                    p.integration(k, 1, mu, f)
+                    p.raycasting(k, mu, f)
             else:
                 p.frame(depth_ptrs[f], poses_cm[f], k32, mu, f)     # set_depth_device + integration + raycasting in one FFI call
             if per_frame_sync:

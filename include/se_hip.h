@@ -197,8 +197,11 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, f
  *      half-sample pyramid of the current depth image, depth2vertex / vertex2normal per level, ICP against vertex_ /
  *      normal_ of the last se_hip_raycast, checkPoseKernel.  The ICP loop is device-resident: one launch per iteration
  *      (k_icp_iter: the previous iteration's final sums + updatePoseKernel -- 6x6 Cholesky solve, SE3 exponential, pose update,
- *      convergence test -- as a prologue, then trackKernel + reduceKernel's partial sums), k_icp_finish (the last iteration's
- *      sums and update, checkPoseKernel, the host record) and k_icp_rows (tracking_result_); the call waits on the host once.
+ *      convergence test -- as a prologue, then trackKernel + reduceKernel's partial sums) and a last launch that is k_icp_finish (the
+ *      last iteration's sums and update, checkPoseKernel, the host record) in its first workgroup and tracking_result_ in the others;
+ *      the pyramid is one launch (copy + two half-samplings), vertices + normals of all levels another.  The call waits on the host
+ *      once for the result; while it enqueues a level's iterations it stays two launches ahead of the device and stops enqueuing a
+ *      level that has converged (the launches left out would have returned at once; SE_HIP_ICP_LOOKAHEAD=0: all up front).
  *      A row-sharded handle must have the peers' rows of vertex_ / normal_ (se_hip_gather_images or se_hip_apply_image_tiles
  *      after the raycast): SE_HIP_E_INVALID otherwise.  se_hip_download_track: `result` of every pixel and error / J of the
  *      accepted ones are the reference's; its rejected pixels keep leftovers of earlier iterations there, zeros here.
@@ -206,6 +209,12 @@ int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, f
  *      level, finest first (default {10, 5, 4}).  Returns 1 = tracked, 0 = gated off or rejected. */
 int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint32_t tracking_rate, uint32_t frame,
                  const int32_t* pyramid, int32_t n_levels, float pose_inout[16]);
+/* One frame of the reference's loop with tracking on (se_apps/src/benchmark.cpp:115-150) in one call:
+ *   float_depth_ = device_depth_m (NULL: keep);  tracked = tracking();  if (tracked || frame <= 3) integration();  raycasting();
+ * pose_inout: pose_ (in), pose_ after tracking (out).  Returns bit 0: integration ran, bit 1: raycasting ran, bit 2: tracked;
+ * < 0 on error.  Same results as se_hip_set_depth_device + se_hip_track + se_hip_integrate + se_hip_raycast. */
+int se_hip_frame_tracked(se_hip_pipeline* p, const float* device_depth_m, const float k[4], float icp_threshold, uint32_t tracking_rate,
+                         const int32_t* pyramid, int32_t n_levels, float pose_inout[16], uint32_t integration_rate, float mu, uint32_t frame);
 /* preprocessing(..., filterInput) (DenseSLAMSystem.cpp:128-141): when on, se_hip_track works on
  * bilateralFilterKernel(float_depth_) (preprocessing.cpp:41-89, gaussian_ of DenseSLAMSystem.cpp:111-118)
  * instead of float_depth_ itself; integration always uses the unfiltered image, as in the reference. */

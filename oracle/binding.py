@@ -262,6 +262,15 @@ def oracle_bilateral_filter(depth):
     return out
 
 
+def oracle_half_sample(depth, e_d: float, r: int = 1):
+    """halfSampleRobustImageKernel (preprocessing.cpp:190-226): one pyramid level down."""
+    lib = load()
+    H, W = depth.shape
+    out = np.empty((H // 2, W // 2), np.float32)
+    lib.so_half_sample(out.reshape(-1), W // 2, H // 2, np.ascontiguousarray(depth, np.float32).reshape(-1), W, e_d, r)
+    return out
+
+
 def oracle_tracking(depth, k, pose, raycast_pose, ref_vertex, ref_normal, icp_threshold=1e-5, pyramid=(10, 5, 4), fma=False):
     """DenseSLAMSystem::tracking on the oracle.  Returns (tracked, new_pose 4x4, TrackData image, reduce row, iterations).
     fma=True: the noise-floor build (-ffp-contract=fast), see oracle/Makefile."""

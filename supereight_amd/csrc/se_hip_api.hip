@@ -144,6 +144,8 @@ struct se_hip_pipeline {
   IcpHostRecord* icp_host = nullptr; // pinned: the one record the host reads per tracked frame
   unsigned reduce_seq = 0;
   int track_iterations = 0;
+  int icp_lookahead = 2;             // launches of a level the host stays ahead of the device (0: all iterations enqueued up front; se_hip_track)
+  bool scan_on_main_once = false;    // se_hip_frame_tracked: this frame's scan follows the ICP on the main stream (nothing to overlap with)
   unsigned char* rgbw = nullptr;   // render target (W*H*4)
   DevMap map{};
   int leaf_level = 0, max_level = 0;
@@ -472,6 +474,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
   if (const char* ev = std::getenv("SE_HIP_OF_SCAN_TILED")) p->of_scan_tiled = std::atoi(ev) != 0;   // A/B knob
   if (const char* ev = std::getenv("SE_HIP_FUSE")) p->fuse = std::atoi(ev) != 0;                     // A/B knob (one-queue streaming schedule)
+  if (const char* ev = std::getenv("SE_HIP_ICP_LOOKAHEAD")) p->icp_lookahead = std::max(0, std::atoi(ev));   // A/B knob (0: every ICP iteration enqueued up front)
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
 #ifdef SE_DIAG
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
@@ -825,7 +828,10 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
   // r04: a deferred raycast of the previous se_hip_frame call is waiting -> this scan rides in its launch, on the main stream (k_raycast_scan)
   const bool fuse_now = p->has_pending && p->in_frame && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1;
-  const bool ov = !fuse_now && p->overlap && (p->sharded || caller_list || p->xgather != nullptr || hipStreamQuery(p->stream) == hipErrorNotReady);
+  // (se_hip_frame_tracked: the main stream still holds the tail of the ICP's last launch, but there is no previous raycast to hide the scan under)
+  const bool chain = p->scan_on_main_once && !p->sharded && !caller_list && p->xgather == nullptr;
+  p->scan_on_main_once = false;
+  const bool ov = !fuse_now && !chain && p->overlap && (p->sharded || caller_list || p->xgather != nullptr || hipStreamQuery(p->stream) == hipErrorNotReady);
   p->scan_on_side = ov;
   hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
@@ -1327,20 +1333,22 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     hipLaunchKernelGGL(k_bilateral_filter, dim3((W + 255) / 256, H), dim3(256), 0, s, p->pyr_depth[0], d0, W, H, G, 0.1f);
     d0 = p->pyr_depth[0];
   }
-  if (!p->filter_input) {
-    // scaled_depth_[0] is a copy of float_depth_ in the reference too (DenseSLAMSystem.cpp:149-152): the tracker's level 0
-    // must not alias an input buffer that the next upload (or the caller, for zero-copy depth) may overwrite
-    HIP_TRY(hipMemcpyAsync(p->pyr_depth[0], d0, (size_t)W * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // scaled_depth_[0] is a copy of float_depth_ in the reference too (DenseSLAMSystem.cpp:149-152): the tracker's level 0 must not alias an input
+  // buffer that the next upload (or the caller, for zero-copy depth) may overwrite.  The copy and the first two half-sampling passes are one launch
+  // (k_depth_pyramid; r04 -- before: a runtime copy, ~20 us of host time in front of the frame's first kernel, and two launches).
+  {
+    float* l1 = n_levels > 1 ? p->pyr_depth[1] : nullptr;
+    float* l2 = n_levels > 2 ? p->pyr_depth[2] : nullptr;
+    hipLaunchKernelGGL(k_depth_pyramid, dim3(((W + 3) / 4 + 255) / 256, (H + 3) / 4), dim3(256), 0, s, p->pyr_depth[0], l1, l2, d0, W, H, 0.1f * 3, p->filter_input ? 0 : 1);   // e_delta * 3
     d0 = p->pyr_depth[0];
   }
   p->scaled0 = d0;
-  for (int i = 1; i < n_levels; ++i) {
+  for (int i = 3; i < n_levels; ++i) {
     const int w = W >> i, h = H >> i;
-    const float* src = i == 1 ? d0 : p->pyr_depth[i - 1];
-    hipLaunchKernelGGL(k_half_sample, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_depth[i], w, h, src, W >> (i - 1), 0.1f * 3, 1);   // e_delta * 3
+    hipLaunchKernelGGL(k_half_sample, dim3((w + 255) / 256, h), dim3(256), 0, s, p->pyr_depth[i], w, h, p->pyr_depth[i - 1], W >> (i - 1), 0.1f * 3, 1);
   }
   {
-    // depth2vertex / vertex2normal of every level: one launch each (grid.z = level; the blocks beyond a coarser level's size return at once)
+    // depth2vertex + vertex2normal of every level: one launch (grid.z = level; the blocks beyond a coarser level's size return at once)
     PyrLevels L{};
     for (int i = 0; i < n_levels; ++i) {
       const float kk[4] = {k[0] / float(1 << i), k[1] / float(1 << i), k[2] / float(1 << i), k[3] / float(1 << i)};
@@ -1350,8 +1358,7 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
       L.depth[i] = i == 0 ? d0 : p->pyr_depth[i];
       L.vertex[i] = p->pyr_vertex[i]; L.normal[i] = p->pyr_normal[i];
     }
-    hipLaunchKernelGGL(k_depth2vertex_levels, dim3((W + 255) / 256, H, n_levels), dim3(256), 0, s, L);
-    hipLaunchKernelGGL(k_vertex2normal_levels, dim3((W + 255) / 256, H, n_levels), dim3(256), 0, s, L, k[1] < 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_vertex_normal_levels, dim3((W + 255) / 256, H, n_levels), dim3(256), 0, s, L, k[1] < 0 ? 1 : 0);
   }
   // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, ONE launch each
   // (k_icp_iter: the previous iteration's final sums + updatePoseKernel as a prologue, then trackKernel + reduceKernel's partial sums); the
@@ -1367,25 +1374,46 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   Pose16 P0;
   for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) P0.m[r * 4 + c] = pose0.m[r][c];
   const size_t part_words = (size_t)8 * SE_TRACK_SEGMENTS * 32;
+  const unsigned seq = ++p->reduce_seq;
+  // A level that has converged turns its remaining launches into launches that return at once (4.4 us each; 7 of the 10 fine-level launches on the
+  // room stream).  The host therefore stays only `look` launches ahead of the device inside a level: every launch reports (launch index, stop flags)
+  // in one pinned word, and before launch j of a level is enqueued the host has seen launch j - look store its state -- once that shows the level's
+  // stop flag, the level's remaining launches (which would only copy the state) are not enqueued.  The result is the same state either way; the
+  // wait is bounded, and a report that does not arrive switches the pruning off for the frame.  SE_HIP_ICP_LOOKAHEAD=0: everything up front (r03).
+  int look = p->icp_lookahead;
+  volatile unsigned long long* prog = &p->icp_host->progress;
   int j = 0, prev_level = -1;
   for (int level = n_levels - 1; level >= 0; --level) {
     a.inW = W / (1 << level); a.inH = H / (1 << level);
     a.level = level;
     for (int i = 0; i < pyramid[level]; ++i, ++j) {
+      if (look > 0 && i >= look + 1) {
+        const unsigned long long need = (unsigned long long)(j - look + 1);
+        unsigned long long v = 0;
+        const bool seen = spin_until([&] { v = *prog; return (unsigned)(v >> 32) == seq && ((v >> 8) & 0xffffffull) >= need; }, 20000);
+        if (!seen) look = 0;
+        else if ((v >> level) & 1ull) break;
+      }
       hipLaunchKernelGGL(k_icp_iter, dim3(SE_TRACK_SEGMENTS, 8), dim3(SE_TRACK_LANES), 0, s, p->icp + (j & 1), p->icp + ((j + 1) & 1), p->pyr_vertex[level],
-                         p->pyr_normal[level], p->vertex, p->normal, p->reduce_partial + ((j + 1) & 1) * part_words, p->reduce_partial + (j & 1) * part_words, a, prev_level, P0);
+                         p->pyr_normal[level], p->vertex, p->normal, p->reduce_partial + ((j + 1) & 1) * part_words, p->reduce_partial + (j & 1) * part_words, a, prev_level, P0,
+                         (unsigned long long*)&p->icp_host->progress, seq, j);
       prev_level = level;
     }
   }
-  const unsigned seq = ++p->reduce_seq;
-  hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(SE_TRACK_LANES), 0, s, p->icp + (j & 1), p->icp + ((j + 1) & 1), p->reduce_partial + ((j + 1) & 1) * part_words,
-                     p->icp_host, W, H, seq, icp_threshold, prev_level, P0);
   p->icp_final = p->icp + ((j + 1) & 1);
-  for (int level = 0; level < n_levels; ++level) {     // tracking_result_: the finest level that ran any iteration (k_icp_rows), with the pose its last iteration used
-    if (pyramid[level] <= 0) continue;
-    a.inW = W / (1 << level); a.inH = H / (1 << level); a.level = level;
-    hipLaunchKernelGGL(k_icp_rows, dim3((a.inW + 255) / 256, a.inH), dim3(256), 0, s, p->icp_final, p->track, p->pyr_vertex[level], p->pyr_normal[level], p->vertex, p->normal, a);
-    break;
+  {
+    // the frame's last launch: k_icp_finish (workgroup (0, 0)) + tracking_result_ of the finest level that ran any iteration (k_icp_rows)
+    int rows_level = -1;
+    for (int level = 0; level < n_levels; ++level) if (pyramid[level] > 0) { rows_level = level; break; }
+    if (rows_level < 0) {
+      hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(SE_TRACK_LANES), 0, s, p->icp + (j & 1), p->icp + ((j + 1) & 1), p->reduce_partial + ((j + 1) & 1) * part_words,
+                         p->icp_host, W, H, seq, icp_threshold, prev_level, P0);
+    } else {
+      a.inW = W / (1 << rows_level); a.inH = H / (1 << rows_level); a.level = rows_level;
+      hipLaunchKernelGGL(k_icp_finish_rows, dim3((a.inW + SE_TRACK_LANES - 1) / SE_TRACK_LANES, a.inH + 1), dim3(SE_TRACK_LANES), 0, s, p->icp + (j & 1), p->icp + ((j + 1) & 1),
+                         p->reduce_partial + ((j + 1) & 1) * part_words, p->icp_host, seq, prev_level, P0, p->track, p->pyr_vertex[rows_level], p->pyr_normal[rows_level],
+                         p->vertex, p->normal, a);
+    }
   }
   HIP_TRY(hipGetLastError());
   // the one host wait of the frame: the record lands in pinned memory (bounded spin, then a stream synchronisation)
@@ -1397,6 +1425,33 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   p->track_iterations = p->icp_host->iterations;
   for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) pose_cm[c * 4 + r] = p->icp_host->pose[r * 4 + c];
   return p->icp_host->tracked ? 1 : 0;
+}
+
+// One frame of the reference's loop with tracking on (se_apps/src/benchmark.cpp:115-150) in one call: float_depth_ hand-over,
+//   tracked = tracking(); if (tracked || frame <= 3) integrated = integration(); raycasting();
+// -- the calls a host makes per frame, without crossing the FFI four times and with the scan chained behind the ICP on the main queue.
+// pose_cm: in = pose_, out = pose_ after tracking.  Returns bit 0: integrated, bit 1: raycast ran, bit 2: tracked.
+int se_hip_frame_tracked(se_hip_pipeline* p, const float* device_depth_m, const float k[4], float icp_threshold, uint32_t tracking_rate,
+                         const int32_t* pyramid, int32_t n_levels, float pose_cm[16], uint32_t integration_rate, float mu, uint32_t frame) {
+  if (int r = check(p)) return r;
+  if (!k || !pose_cm || !pyramid || integration_rate == 0 || tracking_rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (device_depth_m) p->depth = device_depth_m;
+  int out = 0;
+  int r = se_hip_track(p, k, icp_threshold, tracking_rate, frame, pyramid, n_levels, pose_cm);
+  if (r < 0) return r;
+  const bool tracked = r > 0;
+  if (tracked) out |= 4;
+  if (tracked || frame <= 3) {
+    p->scan_on_main_once = true;
+    r = se_hip_integrate(p, pose_cm, k, integration_rate, mu, frame);
+    p->scan_on_main_once = false;
+    if (r < 0) return r;
+    if (r > 0) out |= 1;
+  }
+  r = se_hip_raycast(p, pose_cm, k, mu, frame);
+  if (r < 0) return r;
+  if (r > 0) out |= 2;
+  return out;
 }
 
 int se_hip_filter_depth(se_hip_pipeline* p, int32_t on) {

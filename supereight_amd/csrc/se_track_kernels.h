@@ -56,6 +56,60 @@ __global__ void k_half_sample(float* __restrict__ out, int ow, int oh, const flo
   out[x + y * ow] = t / sum;
 }
 
+// scaled_depth_[0..2] in ONE launch (r04): the copy of float_depth_ into level 0 (DenseSLAMSystem.cpp:149-152) and the two
+// halfSampleRobustImageKernel passes with r = 1 (DenseSLAMSystem.cpp:154-159; preprocessing.cpp:190-226).  A thread owns a 4x4 block of level 0:
+// it stores it, forms the block's four level-1 pixels and from those its one level-2 pixel -- per output pixel the same values in the
+// same order as k_half_sample (window rows outer, columns inner; centre = the window's first pixel), so the images are bit-identical;
+// three launches and two kernel boundaries of an ICP frame's host-bound preamble become one.  l1 / l2 may be null (fewer levels),
+// `store0` = 0 when level 0 is already in place (the bilateral filter wrote it).
+__device__ __forceinline__ float se_half_sample4(float a00, float a01, float a10, float a11, float e_d) {
+  const float center = a00;
+  float sum = 0.0f, t = 0.0f;
+  if (fabsf(a00 - center) < e_d) { sum += 1.0f; t += a00; }
+  if (fabsf(a01 - center) < e_d) { sum += 1.0f; t += a01; }
+  if (fabsf(a10 - center) < e_d) { sum += 1.0f; t += a10; }
+  if (fabsf(a11 - center) < e_d) { sum += 1.0f; t += a11; }
+  return t / sum;
+}
+__global__ __launch_bounds__(256) void k_depth_pyramid(float* __restrict__ l0, float* __restrict__ l1, float* __restrict__ l2, const float* __restrict__ in,
+                                                        int W, int H, float e_d, int store0) {
+  const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y;
+  const int x0 = 4 * bx, y0 = 4 * by;
+  if (x0 >= W || y0 >= H) return;
+  float v[4][4];
+  if ((W & 3) == 0 && y0 + 3 < H) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 q = *reinterpret_cast<const float4*>(in + x0 + (size_t)(y0 + i) * W);
+      v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+      if (store0) *reinterpret_cast<float4*>(l0 + x0 + (size_t)(y0 + i) * W) = q;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool inside = x0 + j < W && y0 + i < H;
+        v[i][j] = inside ? in[x0 + j + (size_t)(y0 + i) * W] : 0.f;
+        if (store0 && inside) l0[x0 + j + (size_t)(y0 + i) * W] = v[i][j];
+      }
+  }
+  if (!l1) return;
+  const int W1 = W >> 1, H1 = H >> 1;
+  float h[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      h[a][b] = se_half_sample4(v[2 * a][2 * b], v[2 * a][2 * b + 1], v[2 * a + 1][2 * b], v[2 * a + 1][2 * b + 1], e_d);
+      const int x1 = 2 * bx + b, y1 = 2 * by + a;
+      if (x1 < W1 && y1 < H1) l1[x1 + (size_t)y1 * W1] = h[a][b];
+    }
+  if (!l2) return;
+  const int W2 = W >> 2, H2 = H >> 2;
+  if (bx < W2 && by < H2) l2[bx + (size_t)by * W2] = se_half_sample4(h[0][0], h[0][1], h[1][0], h[1][1], e_d);
+}
+
 // depth2vertexKernel (preprocessing.cpp:91-111): (depth * invK * Vector4f(x, y, 1, 0)).head<3>()
 struct InvK { float m[12]; };
 __global__ void k_depth2vertex(float* __restrict__ vertex, const float* __restrict__ depth, int W, int H, InvK K) {
@@ -102,6 +156,41 @@ __global__ void k_vertex2normal(float* __restrict__ out, const float* __restrict
   if (negy) { puy = max(y - 1, 0); pdy = min(y + 1, height - 1); }
   else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
   const f3 left = ld3(in, plx + width * y), right = ld3(in, prx + width * y), up = ld3(in, x + width * puy), down = ld3(in, x + width * pdy);
+  if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
+  const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
+  o[0] = n.x; o[1] = n.y; o[2] = n.z;
+}
+
+// depth2vertexKernel + vertex2normalKernel of every level in ONE launch (r04): a pixel's vertex is a function of its own depth and
+// coordinates, so the normal's four neighbour vertices are formed from the depth image (5 x 4 B instead of 5 x 12 B read back from the vertex image
+// a launch later) by the same expression -- bit-identical to the two kernels in sequence, one launch and one boundary less per tracked frame.
+__device__ __forceinline__ f3 se_depth_vertex(const float* __restrict__ depth, int x, int y, int W, const InvK& K) {
+  const float d = depth[x + y * W];
+  f3 v = {0.f, 0.f, 0.f};
+  if (d > 0) {
+    v.x = (((d * K.m[0]) * (float)x + (d * K.m[1]) * (float)y) + (d * K.m[2]) * 1.f) + (d * K.m[3]) * 0.f;
+    v.y = (((d * K.m[4]) * (float)x + (d * K.m[5]) * (float)y) + (d * K.m[6]) * 1.f) + (d * K.m[7]) * 0.f;
+    v.z = (((d * K.m[8]) * (float)x + (d * K.m[9]) * (float)y) + (d * K.m[10]) * 1.f) + (d * K.m[11]) * 0.f;
+  }
+  return v;
+}
+__global__ void k_vertex_normal_levels(PyrLevels L, int negy) {
+  const int l = blockIdx.z, width = L.w[l], height = L.h[l];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  const float* __restrict__ depth = L.depth[l];
+  const InvK& K = L.K[l];
+  const f3 center = se_depth_vertex(depth, x, y, width, K);
+  float* v = L.vertex[l] + 3 * (size_t)(x + y * width);
+  v[0] = center.x; v[1] = center.y; v[2] = center.z;
+  float* o = L.normal[l] + 3 * (size_t)(x + y * width);
+  if (center.z == 0.f) { o[0] = -2.f; return; }
+  const int plx = max(x - 1, 0), prx = min(x + 1, width - 1);
+  int puy, pdy;
+  if (negy) { puy = max(y - 1, 0); pdy = min(y + 1, height - 1); }
+  else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
+  const f3 left = se_depth_vertex(depth, plx, y, width, K), right = se_depth_vertex(depth, prx, y, width, K);
+  const f3 up = se_depth_vertex(depth, x, puy, width, K), down = se_depth_vertex(depth, x, pdy, width, K);
   if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
   const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
   o[0] = n.x; o[1] = n.y; o[2] = n.z;
@@ -189,7 +278,10 @@ struct IcpState {
   int iterations;      // iterations that ran
   int tracked;
 };
-struct IcpHostRecord { float pose[16]; float reduce0[32]; int iterations; int tracked; unsigned seq; };
+struct IcpHostRecord { float pose[16]; float reduce0[32]; int iterations; int tracked; unsigned seq;
+  // (frame seq << 32) | (launches of the frame that have stored their state << 8) | stop flags of the 8 levels: written by every k_icp_iter launch as
+  // one 8-byte store; the host reads it to stop enqueuing a level's remaining iterations once the level has converged (se_hip_track)
+  unsigned long long progress; };
 
 // sin / cos of a float, DEFINED (oracle and device alike, see oracle/se_oracle.cpp so_sincos) as the correctly rounded result:
 // evaluated in double -- Cody-Waite reduction by pi/2 in two parts, the fdlibm kernel polynomials -- and rounded once.  Plain
@@ -339,26 +431,30 @@ __device__ __forceinline__ void se_icp_finalize(IcpShared& sh, const float* __re
 }
 // state[(j + 1) & 1] as iteration j-1's update leaves it (or a plain copy when that iteration did not run)
 // (first: the frame's first launch -- there is no state yet, `p0` is pose_ on entry; this replaces r03's k_icp_begin launch)
-__device__ __forceinline__ void se_icp_store_state(IcpState* __restrict__ so, const IcpState* __restrict__ si, const IcpShared& sh, bool prev_ran, int prev_level,
-                                                   bool first, const Pose16& p0) {
+// Returns (in the lanes of wave 0) the new stop flags as a bit mask.
+__device__ __forceinline__ unsigned se_icp_store_state(IcpState* __restrict__ so, const IcpState* __restrict__ si, const IcpShared& sh, bool prev_ran, int prev_level,
+                                                       bool first, const Pose16& p0) {
   const int t = threadIdx.x;
   if (first) {
     if (t < 16) { so->old_pose[t] = p0.m[t]; so->pose[t] = p0.m[t]; so->last_pose[t] = p0.m[t]; }
     if (t < 32) so->reduce0[t] = 0.f;
     if (t < 8) so->stop[t] = 0;
     if (t == 0) { so->iterations = 0; so->tracked = 0; }
-    return;
+    return 0u;
   }
   if (t < 16) { so->old_pose[t] = si->old_pose[t]; so->pose[t] = prev_ran ? sh.pose[t] : si->pose[t]; so->last_pose[t] = prev_ran ? si->pose[t] : si->last_pose[t]; }
   if (t < 32) so->reduce0[t] = prev_ran ? sh.strip[0][t] : si->reduce0[t];
-  if (t < 8) so->stop[t] = (prev_ran && t == prev_level && sh.conv) ? 1 : si->stop[t];
+  int stop = 0;
+  if (t < 8) { stop = (prev_ran && t == prev_level && sh.conv) ? 1 : si->stop[t]; so->stop[t] = stop; }
   if (t == 0) { so->iterations = si->iterations + (prev_ran ? 1 : 0); so->tracked = si->tracked; }
+  return t < 64 ? (unsigned)(__ballot(stop != 0) & 0xffull) : 0u;
 }
 #define SE_TRACK_BATCH 5   // pixels of one lane whose loads are in flight together (640x480: ceil(1200 / 256))
 __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ inVertex,
                                                               const float* __restrict__ inNormal, const float* __restrict__ refVertex,
                                                               const float* __restrict__ refNormal, const float* __restrict__ partial_prev,
-                                                              float* __restrict__ partial, TrackArgs a, int prev_level, Pose16 p0) {
+                                                              float* __restrict__ partial, TrackArgs a, int prev_level, Pose16 p0,
+                                                              unsigned long long* __restrict__ progress, unsigned seq, int launch) {
   __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
   __shared__ IcpShared sh;
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
@@ -395,7 +491,11 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = first ? p0.m[i] : si->pose[i];
   }
-  if (g == 0 && b == 0) se_icp_store_state(so, si, sh, prev_ran, prev_level, first, p0);
+  if (g == 0 && b == 0) {
+    const unsigned stops = se_icp_store_state(so, si, sh, prev_ran, prev_level, first, p0);
+    // (pinned host memory; one 8-byte store, nothing else to order it with: the host only uses it to stop enqueuing launches that would return at once)
+    if (t == 0 && progress) *(volatile unsigned long long*)progress = ((unsigned long long)seq << 32) | ((unsigned long long)(launch + 1) << 8) | stops;
+  }
   if (stop_cur) return;                 // the level has converged: the reference's `break`
   const float R3[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
   float acc[32];
@@ -487,9 +587,8 @@ __global__ __launch_bounds__(256) void k_icp_rows(const IcpState* __restrict__ s
 
 // The last iteration's prologue work (see k_icp_iter) + checkPoseKernel (tracking.cpp:320-334) + the one record the host reads per
 // frame (pinned memory, sequence word last).  One workgroup of SE_TRACK_LANES threads.
-__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ partial_prev,
-                                                                IcpHostRecord* __restrict__ host, int W, int H, unsigned seq, float icp_threshold, int prev_level, Pose16 p0) {
-  __shared__ IcpShared sh;
+__device__ __forceinline__ void se_icp_finish_wg(IcpShared& sh, const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ partial_prev,
+                                                 IcpHostRecord* __restrict__ host, int W, int H, unsigned seq, float icp_threshold, int prev_level, const Pose16& p0) {
   const int t = threadIdx.x;
   if (prev_level < 0) {   // no iteration was enqueued at all (every pyramid entry 0): the record is the entry pose, sums zero -> rejected, as in the reference
     se_icp_store_state(so, si, sh, false, prev_level, true, p0);
@@ -519,6 +618,37 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish(const IcpState* _
   so->tracked = bad ? 0 : 1;     // (se_icp_store_state's own store to this word was this thread's, earlier in program order)
   __threadfence_system();
   *(volatile unsigned*)&host->seq = seq;
+}
+// (stand-alone: a frame whose pyramid holds no iteration at all)
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ partial_prev,
+                                                                IcpHostRecord* __restrict__ host, int W, int H, unsigned seq, float icp_threshold, int prev_level, Pose16 p0) {
+  __shared__ IcpShared sh;
+  se_icp_finish_wg(sh, si, so, partial_prev, host, W, H, seq, icp_threshold, prev_level, p0);
+}
+// The frame's last launch: workgroup (0, 0) is k_icp_finish -- it is dispatched first, so the host's record is on its way while the other
+// workgroups (grid rows 1..inH) write tracking_result_ (k_icp_rows) with the pose the last iteration that ran tracked with, read from the state
+// as it was BEFORE the finish (si: its `pose` if the last enqueued iteration ran, else `last_pose`).  r04; before, finish and rows were two launches
+// and the rows launch kept the stream busy when the caller's integration() arrived (its scan then took the side queue and an event join).
+__global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish_rows(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ partial_prev,
+                                                                     IcpHostRecord* __restrict__ host, unsigned seq, int prev_level, Pose16 p0,
+                                                                     TrackData* __restrict__ output, const float* __restrict__ inVertex, const float* __restrict__ inNormal,
+                                                                     const float* __restrict__ refVertex, const float* __restrict__ refNormal, TrackArgs a) {
+  __shared__ IcpShared sh;
+  if (blockIdx.y == 0) {
+    if (blockIdx.x == 0) se_icp_finish_wg(sh, si, so, partial_prev, host, a.refW, a.refH, seq, a.icp_threshold, prev_level, p0);
+    return;
+  }
+  const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y - 1;
+  if (px >= a.inW || py >= a.inH) return;
+  const bool prev_ran = si->stop[prev_level] == 0;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = prev_ran ? si->pose[i] : si->last_pose[i];
+  TrackData row;
+  se_track_pixel(row, px, py, inVertex, inNormal, refVertex, refNormal, T, a);
+  TrackData& dst = output[px + py * a.refW];
+  dst.result = row.result;
+  if (row.result == 1) { dst.error = row.error; for (int j = 0; j < 6; ++j) dst.J[j] = row.J[j]; }
 }
 
 // renderTrackKernel (rendering.cpp:154-213)

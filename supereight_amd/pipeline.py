@@ -68,6 +68,8 @@ EXPORTS = {
     "se_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "se_hip_frame_tracked": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_float, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"),
+                                       C.c_int32, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_track": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int32, _f32p]),
     "se_hip_filter_depth": (C.c_int, [C.c_void_p, C.c_int32]),
     "se_hip_download_scaled_depth": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -281,6 +283,22 @@ class DenseSLAMPipeline:
                                               np.asarray(pyramid, np.int32), len(pyramid), pose_cm))
         self.pose_ = pose_cm.reshape(4, 4).T.copy()
         return bool(r)
+
+    _PYRAMID = np.asarray((10, 5, 4), np.int32)
+
+    def frame_tracked(self, depth_ptr: int, k, mu: float, frame: int, icp_threshold: float = 1e-5, tracking_rate: int = 1,
+                      integration_rate: int = 1, pyramid=None) -> int:
+        """One frame of the reference's loop with tracking on (se_apps/src/benchmark.cpp:115-150) in one FFI call: device depth
+        pointer, tracked = tracking(); if tracked or frame <= 3: integration(); raycasting().  pose_ is updated.  Returns bit 0 =
+        integrated, bit 1 = raycast, bit 2 = tracked."""
+        pyr = self._PYRAMID if pyramid is None else np.asarray(pyramid, np.int32)
+        pose_cm = self._pose_cm.copy()
+        r = self._check(self.lib.se_hip_frame_tracked(self._h, C.c_void_p(depth_ptr), self._k(k), icp_threshold, tracking_rate, pyr, len(pyr),
+                                                      pose_cm, integration_rate, mu, frame))
+        if r & 4:
+            self._pose_cm = pose_cm
+            self._pose = pose_cm.reshape(4, 4).T.copy()
+        return r
 
     def track_data(self):
         t = np.zeros(self.W * self.H, self.TRACK_DTYPE)

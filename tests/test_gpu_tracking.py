@@ -111,6 +111,84 @@ def test_slam_loop_with_tracking_on_the_stress_stream():
     cpu.close(); gpu.close()
 
 
+def _tracked_loop(W, H, N, dim, mu, frames, one_call, lookahead=None, odd=False):
+    """The reference's loop with tracking on (se_apps/src/benchmark.cpp:115-150) on the device; returns what a caller can observe per frame."""
+    import os
+    import torch
+    s = SyntheticStream(W, H, dim)
+    old = os.environ.get("SE_HIP_ICP_LOOKAHEAD")
+    if lookahead is not None:
+        os.environ["SE_HIP_ICP_LOOKAHEAD"] = str(lookahead)
+    try:
+        p = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+    finally:
+        if lookahead is not None:
+            if old is None: del os.environ["SE_HIP_ICP_LOOKAHEAD"]
+            else: os.environ["SE_HIP_ICP_LOOKAHEAD"] = old
+    dev = torch.from_numpy(np.stack([s.depth(f) for f in range(frames)])).cuda()
+    p.setPose(s.pose(0))
+    out = []
+    for f in range(frames):
+        if f <= 3:
+            p.setPose(s.pose(f))
+        if one_call and f > 3:
+            r = p.frame_tracked(dev[f].data_ptr(), s.k, mu, f)
+            flags = (bool(r & 4), bool(r & 1), bool(r & 2))
+        else:
+            p.set_depth_device(dev[f].data_ptr())
+            tracked = p.tracking(s.k, 1e-5, 1, f) if f > 3 else False
+            integrated = p.integration(s.k, 1, mu, f) if (tracked or f <= 3) else False
+            flags = (tracked, integrated, p.raycasting(s.k, mu, f))
+        track, red, it = p.track_data() if f > 3 else (None, None, 0)
+        v, n = p.vertex_normal()
+        out.append((flags, p.getPose(), it, red, None if track is None else track["result"].copy(), v, n))
+    blocks = p.blocks()
+    p.close()
+    return out, blocks
+
+
+def test_frame_tracked_is_the_four_calls():
+    """se_hip_frame_tracked (one FFI call per frame, scan chained behind the ICP) == set_depth_device + tracking + integration + raycasting,
+    and pruning a converged level's launches (SE_HIP_ICP_LOOKAHEAD, default 2) == enqueuing every iteration up front (0): poses, iteration
+    counts, sums, tracking_result_, images and the map, bit for bit."""
+    W, H, N, dim, mu, frames = 320, 240, 256, 4.8, 0.1, 10
+    ref, blocks_ref = _tracked_loop(W, H, N, dim, mu, frames, one_call=False, lookahead=0)
+    assert sum(1 for r in ref if r[0][0]) == frames - 4
+    for one_call, look in ((True, 2), (False, 2), (True, 1), (True, 0)):
+        got, blocks = _tracked_loop(W, H, N, dim, mu, frames, one_call=one_call, lookahead=look)
+        for f, (a, b) in enumerate(zip(ref, got)):
+            assert a[0] == b[0], (f, a[0], b[0])
+            assert (a[1].view(np.uint32) == b[1].view(np.uint32)).all(), f
+            assert a[2] == b[2], (f, a[2], b[2])
+            if a[3] is not None:
+                assert (a[3].view(np.uint32) == b[3].view(np.uint32)).all() and (a[4] == b[4]).all(), f
+            assert (a[5].view(np.uint32) == b[5].view(np.uint32)).all() and (a[6].view(np.uint32) == b[6].view(np.uint32)).all(), f
+        for x, y in zip(blocks_ref, blocks):
+            assert (x.view(np.uint8) == y.view(np.uint8)).all()
+
+
+def test_depth_pyramid_of_an_odd_sized_image():
+    """k_depth_pyramid (copy + two half-samplings in one launch) on a size that is not a multiple of 4: the scalar path and the
+    guards of the last column / row, against the oracle's halfSampleRobustImageKernel."""
+    from oracle.binding import oracle_half_sample
+    W, H, N, dim = 322, 242, 128, 4.8
+    s = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim)
+    for f in range(4):
+        p.set_depth(s.depth(f)); p.setPose(s.pose(f))
+        p.integration(s.k, 1, 0.1, f); p.raycasting(s.k, 0.1, f)
+    depth = s.depth(4)
+    p.set_depth(depth)
+    p.tracking(s.k, 1e-5, 1, 4)
+    l0, l1, l2 = p.scaled_depth(0), p.scaled_depth(1), p.scaled_depth(2)
+    assert (l0.view(np.uint32) == depth.view(np.uint32)).all()
+    h1 = oracle_half_sample(depth, 0.1 * 3, 1)
+    h2 = oracle_half_sample(h1, 0.1 * 3, 1)
+    assert l1.shape == h1.shape and l2.shape == h2.shape
+    assert (l1.view(np.uint32) == h1.view(np.uint32)).all() and (l2.view(np.uint32) == h2.view(np.uint32)).all()
+    p.close()
+
+
 def test_tracking_gate_and_rejection():
     W, H, N, dim = 160, 120, 128, 2.4
     s = SyntheticStream(W, H, dim)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# The tracked loop on the GPU box: its parity tests, the host-side A/B (tools/track_probe.py) and a kernel trace of it.
+# usage: tools/gpu_track.sh <tag>
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+T=${1:-r04s}
+mkdir -p gpurun_out
+(time python -m pytest tests/test_gpu_tracking.py tests/test_gpu_asbuilt_tolerance.py -m gpu -x -q --durations=5) > gpurun_out/${T}_pytest_tracking.log 2>&1; tail -8 gpurun_out/${T}_pytest_tracking.log
+python tools/track_probe.py --frames 100 --out gpurun_out/${T}_track_probe.json 2>&1 | cut -c1-260 | tee gpurun_out/${T}_track_probe.log
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_${T}_track -o trk -- python tools/track_probe.py --trace 40 > gpurun_out/${T}_track_trace_run.log 2>&1
+python tools/track_trace_summary.py gpurun_out/prof_${T}_track 20 > gpurun_out/${T}_track_trace_summary.md 2>&1; cat gpurun_out/${T}_track_trace_summary.md
+find gpurun_out/prof_${T}_track -name '*.db' -delete
