@@ -245,6 +245,9 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
     W, H, N, dim, mu = args.width, args.height, args.res, args.dim, args.mu
     poses_cm = [to_colmajor(q) for q in poses]
     k32 = np.ascontiguousarray(k, dtype=np.float32).reshape(4)
+    # (addresses of arrays held above: an array argument costs ctypes microseconds of checks per call, which a closed loop pays per frame)
+    pose_at = [DenseSLAMPipeline.addr(a) for a in poses_cm]
+    k_at = DenseSLAMPipeline.addr(k32)
     out = {}
 
     def run(label, per_frame_sync, track, **kw):
@@ -258,14 +261,14 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
                 t0 = time.perf_counter()
             if track:
                 if f > 3:       # tracking(); if tracked: integration(); raycasting() -- benchmark.cpp:115-150 -- in one FFI call
-                    tracked += (p.frame_tracked(depth_ptrs[f], k32, mu, f) >> 2) & 1
+                    tracked += (p.frame_tracked(depth_ptrs[f], k_at, mu, f) >> 2) & 1
                 else:
                     p.setPose(poses[f])
                     p.set_depth_device(depth_ptrs[f])
                     p.integration(k, 1, mu, f)
                     p.raycasting(k, mu, f)
             else:
-                p.frame(depth_ptrs[f], poses_cm[f], k32, mu, f)     # set_depth_device + integration + raycasting in one FFI call
+                p.frame(depth_ptrs[f], pose_at[f], k_at, mu, f)     # set_depth_device + integration + raycasting in one FFI call
             if per_frame_sync:
                 p.sync()
         p.sync()
@@ -311,12 +314,13 @@ def stress_leg(args, field, device, n: int):
     for label, sync in (("fps", False), ("closed_loop_fps", True)):
         p = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=device)
         _, scratch = prewarm(args, field, ptrs, poses, k32, device)
+        pose_at, k_at = [DenseSLAMPipeline.addr(a) for a in pcm], DenseSLAMPipeline.addr(k32)
         for f in range(warm):
-            p.frame(ptrs[f], pcm[f], k32, mu, f)
+            p.frame(ptrs[f], pose_at[f], k_at, mu, f)
         p.sync()
         t0 = time.perf_counter()
         for f in range(warm, warm + n):
-            p.frame(ptrs[f], pcm[f], k32, mu, f)
+            p.frame(ptrs[f], pose_at[f], k_at, mu, f)
             if sync:
                 p.sync()
         p.sync()
@@ -650,12 +654,14 @@ def main():
         # on this frame's raycast gets; `value` is the pipelined rate of a caller that knows its poses in advance.
         cp = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=local_rank)
         _, cscratch = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else (0, None)
+        # (pose / intrinsics as addresses of the arrays held above: what a C++ caller passes; an array argument costs ctypes 3-5 us of checks)
+        pose_at, k_at = [DenseSLAMPipeline.addr(a) for a in poses_cm], DenseSLAMPipeline.addr(k)
         for f in range(warm):
-            cp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
+            cp.frame(depth_ptrs[f], pose_at[f], k_at, mu, f)
             cp.sync()
         tc0 = time.perf_counter()
         for f in range(warm, warm + K):
-            cp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
+            cp.frame(depth_ptrs[f], pose_at[f], k_at, mu, f)
             cp.sync()
         tc1 = time.perf_counter()
         cp.counts()

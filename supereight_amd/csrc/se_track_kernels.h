@@ -379,6 +379,118 @@ __device__ inline void se_se3_exp(const float a[6], float T[16]) {
   T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
 }
 
+// ---- the same arithmetic spread over the lanes of ONE wave (r04).  The single-lane versions above cost ~1 000 dependent VALU instructions (3 us) in
+// the prologue of every ICP launch.  Here all 64 lanes of wave 0 run the code; what is the same for every lane is computed redundantly (free on a SIMD),
+// and the pieces that are independent of each other go to different lanes: the rows of the Cholesky factor (lane r owns row r: one column step = one
+// multiply-add chain, ONE division), the two sincos calls, the four quaternion divisions, the sixteen entries of the pose product.  Every float operation
+// has the operands and the order it has in se_solve6 / se_se3_exp (sums left to right, true divisions, the same sqrtf): the results are bit-identical,
+// which tests/test_gpu_tracking.py checks against the oracle frame by frame.  SE_ICP_WAVE_SOLVE 0 = the single-lane code (A/B).
+#ifndef SE_ICP_WAVE_SOLVE
+#define SE_ICP_WAVE_SOLVE 1
+#endif
+__device__ __forceinline__ float se_lane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+// vals: b[6], upper triangle[21] (LDS); x: the solution, in every lane.  (Eigen::LLT as in se_solve6.)
+__device__ __forceinline__ void se_solve6_wave(const float* vals, float x[6], int lane) {
+  const int r = lane < 6 ? lane : 5;     // (lanes 6..63 mirror lane 5: defined arithmetic, never read)
+  float Lr[6], diag = 1.f;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if (ok) {
+      const int lo = r < j ? r : j, hi = r < j ? j : r;
+      float w = vals[6 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];     // C[r][j]
+      if (j > 0) {
+        float sp = 0.f;
+#pragma unroll
+        for (int q = 0; q < j; ++q) sp += Lr[q] * se_lane(Lr[q], j);     // L[r][q] * L[j][q]; lane j: L[j][q]^2
+        w -= sp;
+      }
+      const float d = se_lane(w, j);
+      if (!(d > 0.f)) ok = false;      // (same in every lane)
+      else {
+        const float sd = sqrtf(d);
+        const float off = w / sd;
+        Lr[j] = (r == j) ? sd : off;     // (rows above the diagonal hold values nobody reads)
+        if (r == j) diag = sd;
+      }
+    }
+  }
+  if (!ok) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = 0.f;
+    return;
+  }
+  // forward substitution: lane i holds b[i] - sum_{q<i} L[i][q] y[q], subtracted in the order q = 0, 1, ...
+  float v = vals[r], y[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    y[q] = se_lane(v / diag, q);
+    if (q < 5) v -= Lr[q] * y[q];
+  }
+  // backward substitution is a chain (x[i] needs every x[q > i], subtracted in the order q = i+1, ..., 5): every lane runs it on the factor's columns
+  float Lc[6][6], dg[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    dg[i] = se_lane(diag, i);
+#pragma unroll
+    for (int q = i + 1; q < 6; ++q) Lc[q][i] = se_lane(Lr[i], q);
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float u = y[i];
+#pragma unroll
+    for (int q = i + 1; q < 6; ++q) u -= Lc[q][i] * x[q];
+    x[i] = u / dg[i];
+  }
+}
+// se_se3_exp over a wave: T (rows 0..2; row 3 is 0 0 0 1) in every lane
+__device__ __forceinline__ void se_se3_exp_wave(const float a[6], float T[16], int lane) {
+  const float eps = 1e-5f;
+  const float ox = a[3], oy = a[4], oz = a[5];
+  const float theta_sq = (ox * ox + oy * oy) + oz * oz, theta = sqrtf(theta_sq), half_theta = 0.5f * theta;
+  // lane 0: sincos(half_theta), lane 1: sincos(theta) -- evaluated whether or not the small-angle branches below use them
+  float sv, cv;
+  se_sincos_f32((lane & 1) ? theta : half_theta, &sv, &cv);
+  const float sh = se_lane(sv, 0), ch = se_lane(cv, 0), st = se_lane(sv, 1), ct = se_lane(cv, 1);
+  float imag_factor, real_factor;
+  if (theta_sq < eps * eps) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+    real_factor = 1.f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+  } else {
+    imag_factor = sh / theta;
+    real_factor = ch;
+  }
+  float qw = real_factor, qx = imag_factor * ox, qy = imag_factor * oy, qz = imag_factor * oz;
+  const float qn = sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+  {
+    const int c = lane & 3;
+    const float comp = c == 0 ? qw : c == 1 ? qx : c == 2 ? qy : qz;
+    const float nq = comp / qn;
+    qw = se_lane(nq, 0); qx = se_lane(nq, 1); qy = se_lane(nq, 2); qz = se_lane(nq, 3);
+  }
+  const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
+  const float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const float R[3][3] = {{1.f - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1.f - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1.f - (txx + tyy)}};
+  float V[3][3];
+  if (theta < eps) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = R[i][j];
+  } else {
+    const float Om[3][3] = {{0, -oz, oy}, {oz, 0, -ox}, {-oy, ox, 0}};
+    float Om2[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Om2[i][j] = (Om[i][0] * Om[0][j] + Om[i][1] * Om[1][j]) + Om[i][2] * Om[2][j];
+    const float ca = (1.f - ct) / theta_sq, cb = (theta - st) / (theta_sq * theta);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) V[i][j] = ((i == j ? 1.f : 0.f) + ca * Om[i][j]) + cb * Om2[i][j];
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i][j];
+    T[i * 4 + 3] = (V[i][0] * a[0] + V[i][1] * a[1]) + V[i][2] * a[2];
+  }
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
 struct Pose16 { float m[16]; };   // row-major 4x4
 // One ICP iteration = ONE launch, no host in between, no atomics (r04; r03: two launches, k_icp_track + k_icp_update, ~15 us per
 // iteration of which 4.7 us were the single-workgroup update kernel and 3.6 us the two kernel boundaries).
@@ -397,7 +509,7 @@ struct Pose16 { float m[16]; };   // row-major 4x4
 //  k_icp_finish = the prologue once more (the last iteration's sums and update) + checkPoseKernel + the host record.
 // (r03's first single-launch attempt used a last-workgroup ticket and was slower than r02: every workgroup paid an agent-scope fence
 //  and an atomic on one word.)
-struct IcpShared { float strip[8][32]; float pose[16]; int conv; };
+struct IcpShared { float strip[8][32]; float pose[16]; float delta[16]; float prev[16]; int conv; };
 // the rest of iteration `prev`: final sums -> sh.strip[0], pose update -> sh.pose, convergence -> sh.conv; P = the pose it tracked with
 __device__ __forceinline__ void se_icp_finalize(IcpShared& sh, const float* __restrict__ partial, const float* P, float icp_threshold) {
   const int t = threadIdx.x, bb = t >> 5, i = t & 31;
@@ -413,6 +525,30 @@ __device__ __forceinline__ void se_icp_finalize(IcpShared& sh, const float* __re
     sh.strip[0][t] = row0;
   }
   __syncthreads();
+#if SE_ICP_WAVE_SOLVE
+  if (t < 64) {      // wave 0, every lane
+    float x[6], D[16];
+    se_solve6_wave(&sh.strip[0][1], x, t);
+    se_se3_exp_wave(x, D, t);
+    // updatePoseKernel: pose = delta * pose (4x4 product, inner sums left to right) -- lane e forms entry e; delta's row and pose's column reach it through LDS
+    if (t == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { sh.delta[q] = D[q]; sh.prev[q] = P[q]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t < 16) {
+      const int r = t >> 2, c = t & 3;
+      sh.pose[t] = ((sh.delta[r * 4 + 0] * sh.prev[0 * 4 + c] + sh.delta[r * 4 + 1] * sh.prev[1 * 4 + c]) + sh.delta[r * 4 + 2] * sh.prev[2 * 4 + c]) + sh.delta[r * 4 + 3] * sh.prev[3 * 4 + c];
+    }
+    if (t == 0) {
+      float xn = 0.f;
+      for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
+      sh.conv = sqrtf(xn) < icp_threshold ? 1 : 0;
+    }
+  }
+#else
   if (t == 0) {
     float x[6], D[16], N[16];
     se_solve6(&sh.strip[0][1], x);
@@ -427,6 +563,7 @@ __device__ __forceinline__ void se_icp_finalize(IcpShared& sh, const float* __re
     for (int q = 0; q < 6; ++q) xn += x[q] * x[q];
     sh.conv = sqrtf(xn) < icp_threshold ? 1 : 0;
   }
+#endif
   __syncthreads();
 }
 // state[(j + 1) & 1] as iteration j-1's update leaves it (or a plain copy when that iteration did not run)
@@ -455,7 +592,7 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
                                                               const float* __restrict__ refNormal, const float* __restrict__ partial_prev,
                                                               float* __restrict__ partial, TrackArgs a, int prev_level, Pose16 p0,
                                                               unsigned long long* __restrict__ progress, unsigned seq, int launch) {
-  __shared__ float lanes[SE_TRACK_LANES][33];   // +1: bank-conflict padding
+  __shared__ float lanes[SE_TRACK_LANES / 2][33];   // what the upper half of a tree stride hands to the lower half (+1: bank-conflict padding)
   __shared__ IcpShared sh;
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
   const bool first = prev_level < 0;                                    // the frame's first launch: the state is `p0`, nothing has converged
@@ -554,16 +691,31 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
       se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_rows)
     }
   }
+  // the binary tree over the 256 lanes, lane t += lane t + st for st = 128, 64, ..., 1 (the order the oracle fixes).  The sums stay in registers:
+  // for the two strides that cross waves the upper half hands its 32 values over through LDS, the six strides inside wave 0 are lane shuffles
+  // (r04; before, every stride read both operands from LDS and wrote the sum back: 768 LDS instructions on wave 0 instead of 256).
 #pragma unroll
-  for (int i = 0; i < 32; ++i) lanes[t][i] = acc[i];
-  __syncthreads();
-  for (int st = SE_TRACK_LANES / 2; st > 0; st >>= 1) {
+  for (int st = SE_TRACK_LANES / 2; st >= 64; st >>= 1) {
+    if (t >= st && t < 2 * st)
+#pragma unroll
+      for (int i = 0; i < 32; ++i) lanes[t - st][i] = acc[i];
+    __syncthreads();
     if (t < st)
 #pragma unroll
-      for (int i = 0; i < 32; ++i) lanes[t][i] += lanes[t + st][i];
+      for (int i = 0; i < 32; ++i) acc[i] += lanes[t][i];
     __syncthreads();
   }
-  if (t < 32) partial[(b * SE_TRACK_SEGMENTS + g) * 32 + t] = lanes[0][t];
+  if (t < 64) {
+#pragma unroll
+    for (int st = 32; st > 0; st >>= 1)
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] += __shfl_down(acc[i], st, 64);     // (lanes >= st add something irrelevant: only lanes < st are read next)
+    if (t == 0) {
+      float4* dst = reinterpret_cast<float4*>(partial + (size_t)(b * SE_TRACK_SEGMENTS + g) * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+    }
+  }
 }
 
 // tracking_result_ (what renderTrackKernel shows and se_hip_download_track returns) as the reference leaves it after the frame's last

@@ -23,6 +23,10 @@ STAT_NAMES = ("probes", "new_keys", "swept", "nodes", "gets", "interps", "grads"
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _LIB = None
+# The per-frame entry points (se_hip_frame, se_hip_frame_tracked, se_hip_integrate, se_hip_raycast, se_hip_track, ...) take the pose, the
+# intrinsics and the pyramid as plain addresses: an ndpointer argument costs ctypes 3 - 5 us of Python per call (type, dtype and flag checks),
+# two of them were 10 % of a closed-loop frame.  DenseSLAMPipeline checks an array once (_addr) and remembers its address for as long as it
+# holds the array.
 
 
 class SeHipError(RuntimeError):
@@ -48,29 +52,28 @@ EXPORTS = {
     "se_hip_upload_depth": (C.c_int, [C.c_void_p, _f32p]),
     "se_hip_upload_depth_mm": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     "se_hip_set_depth_device": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "se_hip_integrate": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
-    "se_hip_alloc_scan": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_integrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_alloc_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_new_keys_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "se_hip_set_new_keys_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "se_hip_alloc_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
     "se_hip_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "se_hip_alloc_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
-    "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_integrate_sweep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_sweep_shard_bytes": (C.c_size_t, [C.c_size_t]),
     "se_hip_set_sweep_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
     "se_hip_apply_bricks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "se_hip_brick_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "se_hip_raycast": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32]),
+    "se_hip_raycast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]),
     "se_hip_image_tile_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "se_hip_pack_image_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "se_hip_apply_image_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "se_hip_gather_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "se_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32]),
     "se_hip_download_vertex_normal": (C.c_int, [C.c_void_p, _f32p, _f32p]),
     "se_hip_vertex_normal_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
-    "se_hip_frame_tracked": (C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_float, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"),
-                                       C.c_int32, _f32p, C.c_uint32, C.c_float, C.c_uint32]),
-    "se_hip_track": (C.c_int, [C.c_void_p, _f32p, C.c_float, C.c_uint32, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_int32, _f32p]),
+    "se_hip_frame_tracked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32]),
+    "se_hip_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
     "se_hip_filter_depth": (C.c_int, [C.c_void_p, C.c_int32]),
     "se_hip_download_scaled_depth": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "se_hip_download_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -154,6 +157,8 @@ class DenseSLAMPipeline:
         cfg = _Config(self.W, self.H, self.size, self.dim, field_type, device, max_blocks, rb, re_)
         h = C.c_void_p()
         self._h = None
+        self._k_last = self._k_arr = None
+        self._k_addr = 0
         self._check(self.lib.se_hip_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else init_pose
@@ -163,19 +168,45 @@ class DenseSLAMPipeline:
     # modify in place
     @property
     def pose_(self):
+        if self._pose is None:      # the tracker updated the column-major copy in place (tracking, frame_tracked)
+            self._pose = self._pose_cm.reshape(4, 4).T.copy()
         return self._pose
 
     @pose_.setter
     def pose_(self, m):
         self._pose = np.array(m, dtype=np.float32).reshape(4, 4)
         self._pose_cm = np.ascontiguousarray(self._pose.T).reshape(16)
+        self._pose_cm_addr = self._pose_cm.ctypes.data
 
     @staticmethod
-    def _k(k):
-        """float32[4] intrinsics (fx, fy, cx, cy) for the C ABI; no copy if it already is one."""
-        if type(k) is np.ndarray and k.dtype == np.float32 and k.size == 4 and k.flags.c_contiguous:
+    def _addr(a, dtype, size: int) -> int:
+        """Address of a C-contiguous array of `size` elements of `dtype` (checked here: the C ABI takes plain pointers)."""
+        if not (type(a) is np.ndarray and a.dtype == dtype and a.size == size and a.flags.c_contiguous):
+            raise TypeError(f"expected a C-contiguous {np.dtype(dtype).name}[{size}] array")
+        return a.ctypes.data
+
+    def _k(self, k) -> int:
+        """Address of the float32[4] intrinsics (fx, fy, cx, cy) for the C ABI.  An int is taken as the address of such an array that the
+        caller keeps alive (DenseSLAMPipeline.addr).  A float32[4] array is used in place and its address remembered while the caller
+        keeps passing the same object; anything else is converted (and held) on every call."""
+        if type(k) is int:
             return k
-        return np.ascontiguousarray(k, dtype=np.float32).reshape(4)
+        if k is self._k_last:
+            return self._k_addr
+        if type(k) is np.ndarray and k.dtype == np.float32 and k.size == 4 and k.flags.c_contiguous:
+            self._k_last, self._k_arr = k, k
+        else:
+            self._k_last, self._k_arr = None, np.ascontiguousarray(k, dtype=np.float32).reshape(4)
+        self._k_addr = self._k_arr.ctypes.data
+        return self._k_addr
+
+    @staticmethod
+    def addr(a) -> int:
+        """Address of a float32 array for the entry points that accept plain addresses (frame, frame_tracked): check once, call many
+        times.  The caller keeps the array alive and unchanged in size."""
+        if not (type(a) is np.ndarray and a.dtype == np.float32 and a.flags.c_contiguous):
+            raise TypeError("expected a C-contiguous float32 array")
+        return a.ctypes.data
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, status: int) -> int:
@@ -239,16 +270,20 @@ class DenseSLAMPipeline:
         self._check(self.lib.se_hip_set_depth_device(self._h, C.c_void_p(ptr)))
 
     def integration(self, k, integration_rate: int, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_integrate(self._h, self._pose_cm, self._k(k),
+        return bool(self._check(self.lib.se_hip_integrate(self._h, self._pose_cm_addr, self._k(k),
                                                           integration_rate, mu, frame)))
 
     def frame(self, depth_ptr: int, pose_cm, k, mu: float, frame: int, integration_rate: int = 1) -> int:
         """One frame in one FFI call: device depth pointer + integration() + raycasting().  pose_cm = the camera->world pose as
-        16 float32 in column-major order (to_colmajor(pose)); returns bit 0 = integrated, bit 1 = raycast."""
-        return self._check(self.lib.se_hip_frame(self._h, C.c_void_p(depth_ptr), pose_cm, self._k(k), integration_rate, mu, frame))
+        16 float32 in column-major order (to_colmajor(pose)) or the address of such an array (DenseSLAMPipeline.addr: checked once by
+        the caller, who keeps it alive -- the closed loop's per-frame Python cost is what the host adds to the frame); k likewise.
+        Returns bit 0 = integrated, bit 1 = raycast."""
+        if type(pose_cm) is not int:
+            pose_cm = self._addr(pose_cm, np.float32, 16)
+        return self._check(self.lib.se_hip_frame(self._h, depth_ptr, pose_cm, self._k(k), integration_rate, mu, frame))
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm, self._k(k), mu, frame)))
+        return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm_addr, self._k(k), mu, frame)))
 
     def mesh(self) -> np.ndarray:
         """Marching-cubes triangles of the map, (n, 3, 3) float32 vertices in metres (order unspecified)."""
@@ -276,28 +311,32 @@ class DenseSLAMPipeline:
 
     TRACK_DTYPE = np.dtype([("result", np.int32), ("error", np.float32), ("J", np.float32, 6)])
 
-    def tracking(self, k, icp_threshold: float, tracking_rate: int, frame: int, pyramid=(10, 5, 4)) -> bool:
-        """DenseSLAMSystem::tracking: ICP of the current depth image against the last raycast; updates pose_."""
-        pose_cm = _colmajor(self.pose_).copy()
-        r = self._check(self.lib.se_hip_track(self._h, np.asarray(k, np.float32), icp_threshold, tracking_rate, frame,
-                                              np.asarray(pyramid, np.int32), len(pyramid), pose_cm))
-        self.pose_ = pose_cm.reshape(4, 4).T.copy()
-        return bool(r)
-
     _PYRAMID = np.asarray((10, 5, 4), np.int32)
+    _PYRAMID_ADDR = _PYRAMID.ctypes.data
+
+    def _pyr(self, pyramid):
+        if pyramid is None or pyramid is self._PYRAMID or tuple(pyramid) == (10, 5, 4):
+            return self._PYRAMID_ADDR, 3
+        self._pyr_arr = np.ascontiguousarray(pyramid, dtype=np.int32).reshape(-1)
+        return self._pyr_arr.ctypes.data, self._pyr_arr.size
+
+    def tracking(self, k, icp_threshold: float, tracking_rate: int, frame: int, pyramid=None) -> bool:
+        """DenseSLAMSystem::tracking: ICP of the current depth image against the last raycast; updates pose_.
+        pyramid = iterations per level, finest first (default (10, 5, 4))."""
+        pa, n = self._pyr(pyramid)
+        r = self._check(self.lib.se_hip_track(self._h, self._k(k), icp_threshold, tracking_rate, frame, pa, n, self._pose_cm_addr))
+        self._pose = None      # (the column-major copy was updated in place; restored by the library if the check failed)
+        return bool(r)
 
     def frame_tracked(self, depth_ptr: int, k, mu: float, frame: int, icp_threshold: float = 1e-5, tracking_rate: int = 1,
                       integration_rate: int = 1, pyramid=None) -> int:
         """One frame of the reference's loop with tracking on (se_apps/src/benchmark.cpp:115-150) in one FFI call: device depth
         pointer, tracked = tracking(); if tracked or frame <= 3: integration(); raycasting().  pose_ is updated.  Returns bit 0 =
         integrated, bit 1 = raycast, bit 2 = tracked."""
-        pyr = self._PYRAMID if pyramid is None else np.asarray(pyramid, np.int32)
-        pose_cm = self._pose_cm.copy()
-        r = self._check(self.lib.se_hip_frame_tracked(self._h, C.c_void_p(depth_ptr), self._k(k), icp_threshold, tracking_rate, pyr, len(pyr),
-                                                      pose_cm, integration_rate, mu, frame))
-        if r & 4:
-            self._pose_cm = pose_cm
-            self._pose = pose_cm.reshape(4, 4).T.copy()
+        pa, n = self._pyr(pyramid)
+        r = self._check(self.lib.se_hip_frame_tracked(self._h, depth_ptr, self._k(k), icp_threshold, tracking_rate, pa, n,
+                                                      self._pose_cm_addr, integration_rate, mu, frame))
+        self._pose = None
         return r
 
     def track_data(self):
@@ -325,7 +364,7 @@ class DenseSLAMPipeline:
 
     # stage split used by the multi-GPU driver
     def alloc_scan(self, k, integration_rate: int, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_alloc_scan(self._h, self._pose_cm, self._k(k),
+        return bool(self._check(self.lib.se_hip_alloc_scan(self._h, self._pose_cm_addr, self._k(k),
                                                            integration_rate, mu, frame)))
 
     def new_keys_device(self):
@@ -361,7 +400,7 @@ class DenseSLAMPipeline:
         self._check(self.lib.se_hip_brick_exchange(self._h, C.c_void_p(recv_ptr)))
 
     def integrate_sweep(self, k, integration_rate: int, mu: float, frame: int) -> bool:
-        return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, self._pose_cm, self._k(k),
+        return bool(self._check(self.lib.se_hip_integrate_sweep(self._h, self._pose_cm_addr, self._k(k),
                                                                 integration_rate, mu, frame)))
 
     # ------------------------------------------------------------------ outputs

@@ -3,10 +3,17 @@
 # usage: tools/gpu_track.sh <tag>
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=${1:-r04s}
+T=${1:-r04t}
 mkdir -p gpurun_out
 (time python -m pytest tests/test_gpu_tracking.py tests/test_gpu_asbuilt_tolerance.py -m gpu -x -q --durations=5) > gpurun_out/${T}_pytest_tracking.log 2>&1; tail -8 gpurun_out/${T}_pytest_tracking.log
 python tools/track_probe.py --frames 100 --out gpurun_out/${T}_track_probe.json 2>&1 | cut -c1-260 | tee gpurun_out/${T}_track_probe.log
+for lib in gpurun_ab/*.so; do
+  [ -f "$lib" ] || continue
+  for rep in 1 2; do
+    echo "default lib:"; python tools/track_probe.py --trace 100 2>/dev/null | cut -c1-200
+    echo "$lib:"; SE_HIP_LIB=$lib python tools/track_probe.py --trace 100 2>/dev/null | cut -c1-200
+  done
+done 2>&1 | tee gpurun_out/${T}_track_lib_ab.log
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_${T}_track -o trk -- python tools/track_probe.py --trace 40 > gpurun_out/${T}_track_trace_run.log 2>&1
 python tools/track_trace_summary.py gpurun_out/prof_${T}_track 20 > gpurun_out/${T}_track_trace_summary.md 2>&1; cat gpurun_out/${T}_track_trace_summary.md
 find gpurun_out/prof_${T}_track -name '*.db' -delete

@@ -59,15 +59,18 @@ def main():
     ap.add_argument("--res", type=int, default=512); ap.add_argument("--dim", type=float, default=4.8); ap.add_argument("--mu", type=float, default=0.1)
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--trace", type=int, default=0)
+    ap.add_argument("--full", action="store_true", help="every variant, twice (default: three variants, once)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     if a.trace:
         print(json.dumps(run(a, True, int(os.environ.get("SE_HIP_ICP_LOOKAHEAD", "2")), True, a.trace)))
         return
     rows = []
-    for rep in range(2):
+    variants = ((False, 0, True), (False, 2, True), (True, 0, True), (True, 1, True), (True, 2, True), (True, 3, True), (True, 2, False)) if a.full else \
+               ((False, 0, True), (True, 2, True), (True, 2, False))
+    for rep in range(2 if a.full else 1):
         for stream in ("room", "stress"):
-            for one_call, look, sync in ((False, 0, True), (False, 2, True), (True, 0, True), (True, 1, True), (True, 2, True), (True, 3, True), (True, 2, False)):
+            for one_call, look, sync in variants:
                 r = run(a, one_call, look, sync, a.frames, stream=stream)
                 r["rep"] = rep
                 rows.append(r)
