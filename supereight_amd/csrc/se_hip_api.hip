@@ -1402,7 +1402,7 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
   }
   p->icp_final = p->icp + ((j + 1) & 1);
   {
-    // the frame's last launch: k_icp_finish (workgroup (0, 0)) + tracking_result_ of the finest level that ran any iteration (k_icp_rows)
+    // the frame's last launch: k_icp_finish (workgroup (0, 0)) + tracking_result_ of the finest level that ran any iteration
     int rows_level = -1;
     for (int level = 0; level < n_levels; ++level) if (pyramid[level] > 0) { rows_level = level; break; }
     if (rows_level < 0) {

@@ -112,56 +112,14 @@ __global__ __launch_bounds__(256) void k_depth_pyramid(float* __restrict__ l0, f
 
 // depth2vertexKernel (preprocessing.cpp:91-111): (depth * invK * Vector4f(x, y, 1, 0)).head<3>()
 struct InvK { float m[12]; };
-__global__ void k_depth2vertex(float* __restrict__ vertex, const float* __restrict__ depth, int W, int H, InvK K) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= W || y >= H) return;
-  float* v = vertex + 3 * (size_t)(x + y * W);
-  const float d = depth[x + y * W];
-  if (d > 0) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      v[i] = (((d * K.m[i * 4 + 0]) * (float)x + (d * K.m[i * 4 + 1]) * (float)y) + (d * K.m[i * 4 + 2]) * 1.f) + (d * K.m[i * 4 + 3]) * 0.f;
-  } else { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
-}
-
-// all pyramid levels in one launch (blockIdx.z = level): the per-level launches were ~2 us of kernel and ~4 us of launch boundary each
+// all pyramid levels in one launch (blockIdx.z = level): the per-level launches were ~2 us of kernel and ~4 us of launch boundary each (k_vertex_normal_levels)
 struct PyrLevels { float* vertex[8]; float* normal[8]; const float* depth[8]; int w[8], h[8]; InvK K[8]; };
-__global__ void k_depth2vertex_levels(PyrLevels L) {
-  const int l = blockIdx.z, W = L.w[l], H = L.h[l];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= W || y >= H) return;
-  float* v = L.vertex[l] + 3 * (size_t)(x + y * W);
-  const float d = L.depth[l][x + y * W];
-  const InvK& K = L.K[l];
-  if (d > 0) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      v[i] = (((d * K.m[i * 4 + 0]) * (float)x + (d * K.m[i * 4 + 1]) * (float)y) + (d * K.m[i * 4 + 2]) * 1.f) + (d * K.m[i * 4 + 3]) * 0.f;
-  } else { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; }
-}
-
 __device__ __forceinline__ f3 ld3(const float* p, int i) { return {p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]}; }
 __device__ __forceinline__ f3 f3_cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ float f3_dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
-// vertex2normalKernel<NegY> (preprocessing.cpp:113-159); an invalid pixel only gets .x = INVALID, as in the reference
-__global__ void k_vertex2normal(float* __restrict__ out, const float* __restrict__ in, int width, int height, int negy) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= width || y >= height) return;
-  float* o = out + 3 * (size_t)(x + y * width);
-  const f3 center = ld3(in, x + width * y);
-  if (center.z == 0.f) { o[0] = -2.f; return; }
-  const int plx = max(x - 1, 0), prx = min(x + 1, width - 1);
-  int puy, pdy;
-  if (negy) { puy = max(y - 1, 0); pdy = min(y + 1, height - 1); }
-  else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
-  const f3 left = ld3(in, plx + width * y), right = ld3(in, prx + width * y), up = ld3(in, x + width * puy), down = ld3(in, x + width * pdy);
-  if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
-  const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
-  o[0] = n.x; o[1] = n.y; o[2] = n.z;
-}
-
-// depth2vertexKernel + vertex2normalKernel of every level in ONE launch (r04): a pixel's vertex is a function of its own depth and
+// depth2vertexKernel (preprocessing.cpp:91-111) + vertex2normalKernel<NegY> (preprocessing.cpp:113-159; an invalid pixel only gets .x = INVALID, as in
+// the reference) of every level in ONE launch (r04): a pixel's vertex is a function of its own depth and
 // coordinates, so the normal's four neighbour vertices are formed from the depth image (5 x 4 B instead of 5 x 12 B read back from the vertex image
 // a launch later) by the same expression -- bit-identical to the two kernels in sequence, one launch and one boundary less per tracked frame.
 __device__ __forceinline__ f3 se_depth_vertex(const float* __restrict__ depth, int x, int y, int W, const InvK& K) {
@@ -191,24 +149,6 @@ __global__ void k_vertex_normal_levels(PyrLevels L, int negy) {
   else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
   const f3 left = se_depth_vertex(depth, plx, y, width, K), right = se_depth_vertex(depth, prx, y, width, K);
   const f3 up = se_depth_vertex(depth, x, puy, width, K), down = se_depth_vertex(depth, x, pdy, width, K);
-  if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
-  const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
-  o[0] = n.x; o[1] = n.y; o[2] = n.z;
-}
-
-__global__ void k_vertex2normal_levels(PyrLevels L, int negy) {
-  const int l = blockIdx.z, width = L.w[l], height = L.h[l];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= width || y >= height) return;
-  const float* in = L.vertex[l];
-  float* o = L.normal[l] + 3 * (size_t)(x + y * width);
-  const f3 center = ld3(in, x + width * y);
-  if (center.z == 0.f) { o[0] = -2.f; return; }
-  const int plx = max(x - 1, 0), prx = min(x + 1, width - 1);
-  int puy, pdy;
-  if (negy) { puy = max(y - 1, 0); pdy = min(y + 1, height - 1); }
-  else { pdy = max(y - 1, 0); puy = min(y + 1, height - 1); }
-  const f3 left = ld3(in, plx + width * y), right = ld3(in, prx + width * y), up = ld3(in, x + width * puy), down = ld3(in, x + width * pdy);
   if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) { o[0] = -2.f; return; }
   const f3 n = f3_normalized(f3_cross(f3_sub(right, left), f3_sub(up, down)));
   o[0] = n.x; o[1] = n.y; o[2] = n.z;
@@ -272,7 +212,7 @@ __device__ __forceinline__ void se_accumulate_row(float* s, const TrackData& row
 struct IcpState {
   float pose[16];      // current estimate, row-major 4x4 (Ttrack of the next iteration)
   float old_pose[16];  // pose_ on entry (checkPoseKernel restores it)
-  float last_pose[16]; // the pose the last iteration that ran tracked with (k_icp_rows rebuilds tracking_result_ from it)
+  float last_pose[16]; // the pose the last iteration that ran tracked with (k_icp_finish_rows rebuilds tracking_result_ from it)
   float reduce0[32];   // row 0 of reduction_output_ of the last iteration that ran
   int stop[8];         // per pyramid level: the update norm fell below icp_threshold -> the level's remaining iterations are skipped
   int iterations;      // iterations that ran
@@ -688,7 +628,7 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
           }
         }
       }
-      se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_rows)
+      se_accumulate_row(acc, row);     // (tracking_result_ itself is written once per frame, by k_icp_finish_rows)
     }
   }
   // the binary tree over the 256 lanes, lane t += lane t + st for st = 128, 64, ..., 1 (the order the oracle fixes).  The sums stay in registers:
@@ -716,25 +656,6 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
       for (int i = 0; i < 8; ++i) dst[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
     }
   }
-}
-
-// tracking_result_ (what renderTrackKernel shows and se_hip_download_track returns) as the reference leaves it after the frame's last
-// ICP iteration: one launch per tracked frame over the finest level that ran, with the pose that iteration tracked with -- instead
-// of 32 bytes per pixel stored by every one of the 19 iterations (10 MB each on the 640x480 level).  `result` of every pixel and
-// error / J of the accepted ones are the reference's; the reference's rejected pixels keep whatever an earlier iteration or
-// frame left in error / J, which nothing reads.
-__global__ __launch_bounds__(256) void k_icp_rows(const IcpState* __restrict__ s, TrackData* __restrict__ output, const float* __restrict__ inVertex,
-                                                  const float* __restrict__ inNormal, const float* __restrict__ refVertex, const float* __restrict__ refNormal, TrackArgs a) {
-  const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
-  if (px >= a.inW || py >= a.inH) return;
-  float T[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) T[i] = s->last_pose[i];
-  TrackData row;
-  se_track_pixel(row, px, py, inVertex, inNormal, refVertex, refNormal, T, a);
-  TrackData& dst = output[px + py * a.refW];
-  dst.result = row.result;
-  if (row.result == 1) { dst.error = row.error; for (int j = 0; j < 6; ++j) dst.J[j] = row.J[j]; }
 }
 
 // The last iteration's prologue work (see k_icp_iter) + checkPoseKernel (tracking.cpp:320-334) + the one record the host reads per
@@ -777,8 +698,13 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish(const IcpState* _
   __shared__ IcpShared sh;
   se_icp_finish_wg(sh, si, so, partial_prev, host, W, H, seq, icp_threshold, prev_level, p0);
 }
+// tracking_result_ (what renderTrackKernel shows and se_hip_download_track returns) as the reference leaves it after the frame's last
+// ICP iteration: once per tracked frame (k_icp_finish_rows) over the finest level that ran, with the pose that iteration tracked with -- instead
+// of 32 bytes per pixel stored by every one of the 19 iterations (10 MB each on the 640x480 level).  `result` of every pixel and
+// error / J of the accepted ones are the reference's; the reference's rejected pixels keep whatever an earlier iteration or
+// frame left in error / J, which nothing reads.
 // The frame's last launch: workgroup (0, 0) is k_icp_finish -- it is dispatched first, so the host's record is on its way while the other
-// workgroups (grid rows 1..inH) write tracking_result_ (k_icp_rows) with the pose the last iteration that ran tracked with, read from the state
+// workgroups (grid rows 1..inH) write tracking_result_ with the pose the last iteration that ran tracked with, read from the state
 // as it was BEFORE the finish (si: its `pose` if the last enqueued iteration ran, else `last_pose`).  r04; before, finish and rows were two launches
 // and the rows launch kept the stream busy when the caller's integration() arrived (its scan then took the side queue and an event join).
 __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_finish_rows(const IcpState* __restrict__ si, IcpState* __restrict__ so, const float* __restrict__ partial_prev,

@@ -167,6 +167,31 @@ def test_frame_tracked_is_the_four_calls():
             assert (x.view(np.uint8) == y.view(np.uint8)).all()
 
 
+def test_frame_tracked_does_not_integrate_a_rejected_frame():
+    """benchmark.cpp:141-147: integration only if tracking succeeded (or frame <= 3); the raycast runs either way, from the restored pose."""
+    import torch
+    W, H, N, dim, mu = 160, 120, 128, 2.4, 0.1
+    s = SyntheticStream(W, H, dim)
+    p = DenseSLAMPipeline((W, H), N, dim)
+    dev = torch.from_numpy(np.stack([s.depth(f) for f in range(6)])).cuda()
+    for f in range(4):
+        p.setPose(s.pose(f))
+        r = p.frame_tracked(dev[f].data_ptr(), s.k, mu, f)          # frames 0..3: tracking cannot succeed before the first raycast (frame 3), integration runs anyway
+        assert r & 1 and not (r & 4) and bool(r & 2) == (f > 2), (f, r)
+    before = [x.copy() for x in p.blocks()]
+    far = p.getPose().copy(); far[:3, 3] += 1.0                     # nothing overlaps from here: checkPoseKernel rejects and restores
+    p.setPose(far)
+    r = p.frame_tracked(dev[4].data_ptr(), s.k, mu, 4)
+    assert r == 2, r                                                # not tracked, not integrated, raycast ran
+    assert (p.getPose() == far).all()
+    after = p.blocks()
+    for x, y in zip(before, after):
+        assert x.shape == y.shape and (x.view(np.uint8) == y.view(np.uint8)).all()
+    p.setPose(s.pose(3))
+    assert p.frame_tracked(dev[5].data_ptr(), s.k, mu, 5, tracking_rate=2) == 2     # frame % tracking_rate != 0: tracking() returns false
+    p.close()
+
+
 def test_depth_pyramid_of_an_odd_sized_image():
     """k_depth_pyramid (copy + two half-samplings in one launch) on a size that is not a multiple of 4: the scalar path and the
     guards of the last column / row, against the oracle's halfSampleRobustImageKernel."""
