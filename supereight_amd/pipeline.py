@@ -148,6 +148,10 @@ def _colmajor(m) -> np.ndarray:
 
 
 class DenseSLAMPipeline:
+    # (class-level defaults: an object that adopts a handle made by se_hip_create_replicas does not run __init__)
+    _k_last = _k_arr = _pyr_arr = None
+    _k_addr = 0
+
     def __init__(self, input_size, volume_resolution: int, volume_dimension: float, init_pose=None,
                  field_type: int = SDF, device: int = 0, max_blocks: int = 0, rows=None):
         self.lib = load_library()
@@ -157,8 +161,6 @@ class DenseSLAMPipeline:
         cfg = _Config(self.W, self.H, self.size, self.dim, field_type, device, max_blocks, rb, re_)
         h = C.c_void_p()
         self._h = None
-        self._k_last = self._k_arr = None
-        self._k_addr = 0
         self._check(self.lib.se_hip_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else init_pose
