@@ -60,7 +60,7 @@ typedef struct se_hip_config {
   float volume_dimension;    /* metres per side */
   int32_t field_type;        /* SE_HIP_FIELD_* */
   int32_t device;            /* HIP device ordinal */
-  int64_t max_blocks;        /* capacity of the voxel-block pool; 0 = default */
+  int64_t max_blocks;        /* capacity of the voxel-block pool; 0 = default (a dense brick grid while it costs <= 16 GiB, else 24 (N/8)^2 pooled bricks) */
   int32_t row_begin;         /* image rows [row_begin,row_end) this handle alloc-scans and */
   int32_t row_end;           /*   raycasts (multi-GPU tile sharding); 0,0 = the whole image */
 } se_hip_config;

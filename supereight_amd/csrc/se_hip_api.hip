@@ -501,13 +501,18 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   // Pooled mode (max_blocks > 0, or a grid that does not fit): max_blocks bricks behind the index.
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  // r04: a dense grid is the default only while it costs <= 16 GiB (<= 1024^3).  Beyond that (2048^3: 64 GiB for a ~2 GB payload) the
-  // default is the pooled layout with room for 1/20 of the grid's cells -- 3.2 GiB of bricks at 2048^3, 7x the blocks the benchmark stream
-  // allocates there; a pool that runs out is reported (SE_HIP_E_CAPACITY), max_blocks raises it.  Measured with the lean pooled march
-  // (profiles/r04h_pooled_vs_dense.log): pooled is 2.6 % / 3.0 % behind dense in frames/s at 1024^3 / 2048^3 and 25 % behind at 512^3.
-  bool dense = cfg->max_blocks <= 0 && cells * 4096 <= free_b / 3 && cells * 4096 <= ((size_t)16 << 30);
+  // r04: a dense grid is the default only while it costs <= SE_HIP_DENSE_MAX_GIB (see below).  Beyond that (2048^3: 64 GiB for a ~2 GB payload) the
+  // default is the pooled layout.  Its default capacity follows what a scan can allocate -- surfaces, not volume: four layers of blocks on each of the
+  // six faces of the volume's cube, 24 (N/8)^2 bricks (1.5 GiB at 1024^3, 6 GiB at 2048^3; 4-5x what the benchmark streams allocate there), at least
+  // 65 536; a pool that runs out is reported (SE_HIP_E_CAPACITY), max_blocks raises it.  Measured with the lean pooled march
+  // (profiles/r04h_pooled_vs_dense.log, two queues): pooled is 2.6 % / 3.0 % behind dense in frames/s at 1024^3 / 2048^3 and 25 % behind at 512^3.
+  size_t dense_max_gib = 16;
+  if (const char* ev = std::getenv("SE_HIP_DENSE_MAX_GIB")) dense_max_gib = (size_t)std::max(0, std::atoi(ev));
+  bool dense = cfg->max_blocks <= 0 && cells * 4096 <= free_b / 3 && cells * 4096 <= (dense_max_gib << 30);
   if (const char* ev = std::getenv("SE_HIP_DENSE")) dense = std::atoi(ev) != 0 && cells * 4096 <= free_b / 2;
-  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : (dense ? cells : std::max((size_t)1 << 16, ((cells / 20 + 4095) / 4096) * 4096));
+  const size_t nb_side = (size_t)cfg->volume_resolution / 8;
+  const size_t cap_default = std::max((size_t)1 << 16, ((24 * nb_side * nb_side + 4095) / 4096) * 4096);
+  size_t cap = cfg->max_blocks > 0 ? (size_t)cfg->max_blocks : (dense ? cells : std::max((size_t)1 << 16, std::min(cap_default, free_b / 3 / 4096)));
   cap = std::min(cap, cells);
   m.dense = dense ? 1 : 0;
   const size_t slots = dense ? cells : cap;   // voxel bricks / active flags
