@@ -167,6 +167,38 @@ def test_frame_tracked_is_the_four_calls():
             assert (x.view(np.uint8) == y.view(np.uint8)).all()
 
 
+@pytest.mark.parametrize("pyramid", [(6,), (5, 4), (4, 3, 2, 2), (0, 5, 4)], ids=["1-level", "2-levels", "4-levels", "no-fine-level"])
+def test_tracking_with_other_pyramids(pyramid):
+    """k_depth_pyramid with one / two levels (no l1 / l2), k_half_sample for the levels beyond the third, and a pyramid whose finest level has no
+    iteration (tracking_result_ then comes from level 1): decision, iteration count, sums, TrackData and pose against the oracle, bit for bit."""
+    W, H, N, dim, mu = 320, 240, 256, 4.8, 0.1
+    s = SyntheticStream(W, H, dim)
+    cpu = OraclePipeline(SDF, N, dim, W, H)
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+    v_c = n_c = rp_c = None
+    for f in range(5):
+        depth, pose = s.depth(f), s.pose(f)
+        gpu.set_depth(depth); gpu.setPose(pose)
+        cpu.integrate(depth, pose, s.k, mu, f); gpu.integration(s.k, 1, mu, f)
+        ran, vv, nn = cpu.raycast(pose, s.k, mu, f); gpu.raycasting(s.k, mu, f)
+        if ran:
+            v_c, n_c, rp_c = vv, nn, pose.copy()
+    depth = s.depth(5)
+    gpu.set_depth(depth)
+    ok_c, pose_c, track_c, red_c, it_c = oracle_tracking(depth, s.k, s.pose(4), rp_c, v_c, n_c, 1e-5, pyramid)
+    ok_g = gpu.tracking(s.k, 1e-5, 1, 5, pyramid)
+    track_g, red_g, it_g = gpu.track_data()
+    assert ok_g == ok_c and it_g == it_c and it_c > 0
+    assert (red_g.view(np.uint32) == red_c.view(np.uint32)).all()
+    assert (gpu.getPose().view(np.uint32) == pose_c.view(np.uint32)).all()
+    lvl = next(i for i, n in enumerate(pyramid) if n > 0)              # tracking_result_ holds the finest level that ran (row stride = W)
+    w, h = W >> lvl, H >> lvl
+    assert (track_g["result"][:h, :w] == track_c["result"][:h, :w]).all()
+    good = track_c["result"][:h, :w] == 1
+    assert (track_g["J"][:h, :w][good].view(np.uint32) == track_c["J"][:h, :w][good].view(np.uint32)).all()
+    cpu.close(); gpu.close()
+
+
 def test_frame_tracked_does_not_integrate_a_rejected_frame():
     """benchmark.cpp:141-147: integration only if tracking succeeded (or frame <= 3); the raycast runs either way, from the restored pose."""
     import torch
