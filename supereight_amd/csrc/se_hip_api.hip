@@ -140,7 +140,6 @@ struct se_hip_pipeline {
   TrackData* track = nullptr;
   float* reduce_partial = nullptr;   // 8 x SE_TRACK_SEGMENTS x 32 partial sums of the running ICP iteration
   IcpState* icp = nullptr;           // device: what one ICP iteration hands to the next (two copies: launch j reads [j & 1], writes [(j + 1) & 1])
-  IcpState* icp_final = nullptr;     // the copy k_icp_finish of the last se_hip_track wrote
   IcpHostRecord* icp_host = nullptr; // pinned: the one record the host reads per tracked frame
   unsigned reduce_seq = 0;
   int track_iterations = 0;
@@ -1365,10 +1364,10 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     }
     hipLaunchKernelGGL(k_vertex_normal_levels, dim3((W + 255) / 256, H, n_levels), dim3(256), 0, s, L, k[1] < 0 ? 1 : 0);
   }
-  // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: every iteration of every level is enqueued now, ONE launch each
+  // The ICP loop (DenseSLAMSystem.cpp:165-186) is device-resident: the iterations of every level are enqueued from here, ONE launch each
   // (k_icp_iter: the previous iteration's final sums + updatePoseKernel as a prologue, then trackKernel + reduceKernel's partial sums); the
   // pose, the convergence flags and the sums travel from launch to launch in device memory (double-buffered), and the host reads one
-  // pinned record when k_icp_finish has run.
+  // pinned record when the frame's last launch (k_icp_finish_rows) has run its first workgroup.
   const M4 pose0 = from_colmajor(pose_cm);
   const M4 projectReference = mul(camera_matrix(k), rigid_inverse(from_colmajor(p->raycast_pose)));
   TrackArgs a{};
@@ -1405,7 +1404,6 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
       prev_level = level;
     }
   }
-  p->icp_final = p->icp + ((j + 1) & 1);
   {
     // the frame's last launch: k_icp_finish (workgroup (0, 0)) + tracking_result_ of the finest level that ran any iteration
     int rows_level = -1;
