@@ -31,6 +31,9 @@
                         // 248 -> 257 us at 2048^3 (4 samples: equal): the extra samples are ~30 VALU instructions and two cold lines each, for
                         // every lane of a wave in which any lane is in that state, and half of them are fetched past the end of the walk.
 #endif
+#ifndef SE_FUSED_RAY_PRIO
+#define SE_FUSED_RAY_PRIO 1   // k_raycast_scan at <= 512^3: raycast waves start at issue priority 1 instead of 0 (A/B: profiles/r04x_fused_ray_prio_ab.log)
+#endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
 #ifndef SE_COST_BATCH
 #define SE_COST_BATCH 5   // raycast scheduling: cost of a tile = trips of its slowest ray + SE_COST_BATCH * its march batches (fitted against per-wave clocks in r02)
@@ -2528,7 +2531,14 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast_scan(DevMap m,
       else { const int k = j - 2 * I; is_scan = (ray_wgs - F > I) ? 0 : 1; bid = is_scan ? I + k : F + I + k; }
     }
   }
-  if (!is_scan) { se_raycast_wg<OFUSION, false, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, bid); return; }
+  if (!is_scan) {
+    // the raycast's waves are the launch's critical path: they start at issue priority 1, the scan's (priority 0) take the slots they leave.  Same box,
+    // two repetitions (profiles/r04x_fused_ray_prio_ab.log): +1.1 % frames/s at 512^3, +2 % OFusion, 0 on the stress stream, -1 % at 1024^3 (there the scan,
+    // 2x as long, ends the launch when it is held back) -> volumes whose every level is staged (<= 512^3) only
+    if (SE_FUSED_RAY_PRIO && SHALLOW) __builtin_amdgcn_s_setprio(1);
+    se_raycast_wg<OFUSION, false, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, bid);
+    return;
+  }
   if (OFUSION) se_scan_ofusion_wg<false>(ms, depthmap, sa, bid);
   else se_scan_sdf_wg<false, DENSE>(ms, depthmap, sa, smem, bid);   // (its SE_SCAN_SLOTS * SE_WG_SCAN words fit the raycast's LDS allocation: checked by the host)
 }
