@@ -35,6 +35,9 @@
 #define SE_FUSED_RAY_PRIO 1   // k_raycast_scan at <= 512^3: raycast waves start at issue priority 1 instead of 0 (A/B: profiles/r04x_fused_ray_prio_ab.log)
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
+#ifndef SE_OF_PREFETCH
+#define SE_OF_PREFETCH 0   // OFusion march on the dense grid: interpolation corners of this many samples per round trip (0: each interpolation fetches its own; se_cast_ray_of_lean)
+#endif
 #ifndef SE_COST_BATCH
 #define SE_COST_BATCH 5   // raycast scheduling: cost of a tile = trips of its slowest ray + SE_COST_BATCH * its march batches (fitted against per-wave clocks in r02)
 #endif
@@ -2124,6 +2127,58 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) { qx[i] = A::ldx(m, sm[i].vi); qy[i] = A::ldy(m, sm[i].vi); }
     bool stop = false;
+#if SE_OF_PREFETCH
+    // Inside the band in front of a surface EVERY sample is interpolated (x > -100 && y > 0: observed) until the hit: up to eight dependent round
+    // trips per batch when each interpolation fetches its own corners.  Here the samples of a batch are taken SE_OF_PREFETCH at a time: the corner
+    // values of those that will be interpolated (known from the batch's own x / y, already here) are fetched together, then the samples are consumed
+    // in order from registers -- same values, same operations, same order; corners of samples behind a hit were fetched for nothing.
+    unsigned obs = 0u;      // bit i: sample i exists (t < tfar) and is observed
+#pragma unroll
+    for (int i = 0; i < SE_SPEC_OF; ++i) {
+      const float dx = sm[i].in ? qx[i] : fc.init_x, dy = sm[i].in ? qy[i] : fc.init_y;
+      if (tt[i] < tfar && dx > -100.f && dy > 0.f) obs |= 1u << i;
+    }
+#pragma unroll
+    for (int h = 0; h < SE_SPEC_OF / SE_OF_PREFETCH; ++h) {
+      float pc[SE_OF_PREFETCH][8], cfx[SE_OF_PREFETCH], cfy[SE_OF_PREFETCH], cfz[SE_OF_PREFETCH];
+      bool inside[SE_OF_PREFETCH];
+#pragma unroll
+      for (int j = 0; j < SE_OF_PREFETCH; ++j) {
+        const int i = SE_OF_PREFETCH * h + j;
+        inside[j] = false;
+        if (!stop && ((obs >> i) & 1u)) {
+          const SeCell<O32> cell = se_cell_lean<O32>(m, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, tt[i]))));
+          inside[j] = cell.inside;
+          cfx[j] = cell.fx; cfy[j] = cell.fy; cfz[j] = cell.fz;
+          if (cell.inside) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pc[j][k] = A::ldx(m, cell.vi[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < SE_OF_PREFETCH; ++j) {
+        const int i = SE_OF_PREFETCH * h + j;
+        if (stop) continue;
+        t = tt[i];
+        if (!(t < tfar)) { done = true; stop = true; continue; }
+        if (STATS) ++rc.n_get;
+        if ((obs >> i) & 1u) {
+          if (inside[j]) {
+            const float fx = cfx[j], fy = cfy[j], fz = cfz[j];
+            const float* pk = pc[j];
+            f_tt = (((pk[0] * (1 - fx) + pk[1] * fx) * (1 - fy) + (pk[2] * (1 - fx) + pk[3] * fx) * fy) * (1 - fz) +
+                    ((pk[4] * (1 - fx) + pk[5] * fx) * (1 - fy) + (pk[6] * (1 - fx) + pk[7] * fx) * fy) * fz);
+          } else {
+            f_tt = se_interp_generic<true>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, tt[i]))), c);   // a corner outside the volume
+          }
+          if (STATS) ++rc.n_interp;
+        }
+        if (f_tt > 0.f) { done = true; stop = true; continue; }
+        f_t = f_tt;
+      }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) {
       if (stop) continue;
@@ -2138,6 +2193,7 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
       if (f_tt > 0.f) { done = true; stop = true; continue; }
       f_t = f_tt;
     }
+#endif
     if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
   }
   if (f_tt > 0.f) {
