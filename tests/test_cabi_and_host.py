@@ -142,3 +142,41 @@ def test_one_hip_runtime_per_process():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-2:] == ["1", "1"], out.stdout
+
+
+def test_pipeline_passes_remembered_addresses():
+    """The per-frame entry points take pose / intrinsics / pyramid as plain addresses (an ndpointer argument costs ctypes microseconds of checks
+    per call): DenseSLAMPipeline checks an array once, holds it and remembers where it lives.  Host logic only -- no library call."""
+    import ctypes as C
+    from supereight_amd.pipeline import EXPORTS, DenseSLAMPipeline
+    p = DenseSLAMPipeline.__new__(DenseSLAMPipeline)          # (no handle: the helpers under test make no C call)
+    # pose_: row-major 4x4 in, column-major copy held, its address remembered, the 4x4 rebuilt lazily after an in-place update by the library
+    m = np.arange(16, dtype=np.float64).reshape(4, 4)
+    p.pose_ = m
+    assert p._pose_cm.dtype == np.float32 and p._pose_cm_addr == p._pose_cm.ctypes.data
+    assert (p._pose_cm == m.T.reshape(16)).all() and (p.pose_ == m).all()
+    p._pose_cm[12] = 42.0; p._pose = None                      # what tracking() / frame_tracked() do after the call
+    assert p.pose_[0, 3] == 42.0 and p.getPose() is not p.pose_
+    # intrinsics: a float32[4] array is used in place and remembered by identity; anything else is converted and held
+    k = np.array([481.2, 480.0, 320.0, 240.0], np.float32)
+    a = p._k(k)
+    assert a == k.ctypes.data and p._k(k) == a
+    k[0] = 500.0                                               # in-place change of the caller's array: the address still shows it
+    assert C.cast(p._k(k), C.POINTER(C.c_float))[0] == 500.0
+    b = p._k([1.0, 2.0, 3.0, 4.0])
+    assert b != a and [C.cast(b, C.POINTER(C.c_float))[i] for i in range(4)] == [1.0, 2.0, 3.0, 4.0]
+    assert p._k(k.astype(np.float64)) != a and p._k(k) == a and p._k(12345) == 12345
+    # pyramid: the default is one shared array; others are converted and held
+    assert p._pyr(None) == p._pyr((10, 5, 4)) == (DenseSLAMPipeline._PYRAMID_ADDR, 3)
+    pa, n = p._pyr([4, 3])
+    assert n == 2 and [C.cast(pa, C.POINTER(C.c_int32))[i] for i in range(2)] == [4, 3]
+    # addr(): what callers of frame() / frame_tracked() pass for arrays they hold themselves
+    pose_cm = np.zeros(16, np.float32)
+    assert DenseSLAMPipeline.addr(pose_cm) == pose_cm.ctypes.data
+    with pytest.raises(TypeError):
+        DenseSLAMPipeline.addr(np.zeros(16, np.float64))
+    with pytest.raises(TypeError):
+        DenseSLAMPipeline._addr(np.zeros(12, np.float32), np.float32, 16)
+    # the declared argument types of the per-frame entry points are addresses, not array checkers
+    for name in ("se_hip_frame", "se_hip_frame_tracked", "se_hip_integrate", "se_hip_raycast", "se_hip_track", "se_hip_alloc_scan", "se_hip_integrate_sweep"):
+        assert all(t in (C.c_void_p, C.c_float, C.c_uint32, C.c_int32) for t in EXPORTS[name][1]), name
