@@ -1262,16 +1262,27 @@ __device__ __forceinline__ float se_interp_generic(const DevMap& m, const FieldC
     e[k] = 0u;
     if (need) e[k] = se_block_entry<DENSE>(m, (lx + (k & 1)) >> 3, (ly + ((k >> 1) & 1)) >> 3, (lz + (k >> 2)) >> 3, c);
   }
-  // phase 2: the 8 corner values
+  // phase 2: the 8 corner values.  Corner (i, j, k) lies in block (i && cx, j && cy, k && cz) of the 2x2x2 candidates: the entry is picked axis by
+  // axis (12 selects for the cell; r04 -- a chain of seven compares and selects per corner before) and the voxel offset is a sum of per-axis terms
+  uint32_t ex1[4], exy[2][2][2];     // ex1[q] = the x-upper corner's entry for (y, z) block pair q; exy[i][j][s] after the y step
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ex1[q] = cx ? e[2 * q + 1] : e[2 * q];
+#pragma unroll
+  for (int sz = 0; sz < 2; ++sz) {
+    exy[0][0][sz] = e[4 * sz];
+    exy[1][0][sz] = ex1[2 * sz];
+    exy[0][1][sz] = cy ? e[4 * sz + 2] : e[4 * sz];
+    exy[1][1][sz] = cy ? ex1[2 * sz + 1] : ex1[2 * sz];
+  }
+  const uint32_t ox[2] = {(uint32_t)lx & 7u, (uint32_t)(lx + 1) & 7u};
+  const uint32_t oy[2] = {((uint32_t)ly & 7u) << 3, ((uint32_t)(ly + 1) & 7u) << 3};
+  const uint32_t oz[2] = {((uint32_t)lz & 7u) << 6, ((uint32_t)(lz + 1) & 7u) << 6};
   float p[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int kk = (cx ? (k & 1) : 0) | (cy ? (k & 2) : 0) | (cz ? (k & 4) : 0);
-    uint32_t ek = e[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) ek = (kk == j) ? e[j] : ek;
-    const int x = lx + (k & 1), y = ly + ((k >> 1) & 1), z = lz + (k >> 2);
-    const size_t vi = ek ? se_voxel_index(ek, x, y, z) : 0;
+    const int i = k & 1, j = (k >> 1) & 1, kz = k >> 2;
+    const uint32_t ek = kz ? (cz ? exy[i][j][1] : exy[i][j][0]) : exy[i][j][0];
+    const size_t vi = ek ? (size_t)(ek - 1u) * SE_BRICK_STRIDE + (size_t)(ox[i] + oy[j] + oz[kz]) : 0;
     const float v = m.vx[vi];
     p[k] = ek ? v : missing;
   }
@@ -1353,25 +1364,39 @@ __device__ __forceinline__ f3 se_grad_generic(const DevMap& m, const FieldConst 
   uint32_t e[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) e[k] = se_block_entry<DENSE>(m, (k & 1) ? xb1 : xb0, (k & 2) ? yb1 : yb0, (k & 4) ? zb1 : zb0, c);
-  // phase 2: the 32 voxels
+  // phase 2: the 32 voxels.  A voxel's block among the 2x2x2 candidates is (x block != xb0, y block != yb0, z block != zb0): the brick base is
+  // picked axis by axis (x: 16 selects, y: 32, z: one per voxel; r04 -- seven compares and selects per voxel before) and the offset inside the
+  // brick is a sum of per-axis terms.  `base` = brick offset + 1 in voxels' units (0: no brick), so that "missing" stays one test.
+  bool ux[4], uy[4], uz[4];
+  uint32_t ox[4], oy[4], oz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ux[i] = (X[i] >> 3) != xb0; uy[i] = (Y[i] >> 3) != yb0; uz[i] = (Z[i] >> 3) != zb0;
+    ox[i] = (uint32_t)X[i] & 7u; oy[i] = ((uint32_t)Y[i] & 7u) << 3; oz[i] = ((uint32_t)Z[i] & 7u) << 6;
+  }
+  uint32_t ex[4][4];        // [xi][q]: entry of x-voxel xi in the (y, z) block pair q
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ex[xi][q] = ux[xi] ? e[2 * q + 1] : e[2 * q];
   float V[4][4][4];
 #pragma unroll
-  for (int zi = 0; zi < 4; ++zi)
+  for (int yi = 0; yi < 4; ++yi)
 #pragma unroll
-    for (int yi = 0; yi < 4; ++yi)
+    for (int xi = 0; xi < 4; ++xi) {
+      if (!((xi == 1 || xi == 2) || (yi == 1 || yi == 2))) continue;      // (no voxel of this column is needed)
+      const uint32_t exy0 = uy[yi] ? ex[xi][1] : ex[xi][0], exy1 = uy[yi] ? ex[xi][3] : ex[xi][2];
+      const uint32_t oxy = ox[xi] + oy[yi];
 #pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
+      for (int zi = 0; zi < 4; ++zi) {
         const int central = (xi == 1 || xi == 2) + (yi == 1 || yi == 2) + (zi == 1 || zi == 2);
         if (central < 2) continue;
-        const int x = X[xi], y = Y[yi], z = Z[zi];
-        const int kk = ((x >> 3) != xb0 ? 1 : 0) | ((y >> 3) != yb0 ? 2 : 0) | ((z >> 3) != zb0 ? 4 : 0);
-        uint32_t ek = e[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) ek = (kk == j) ? e[j] : ek;
-        const size_t vi = ek ? se_voxel_index(ek, x, y, z) : 0;
+        const uint32_t ek = uz[zi] ? exy1 : exy0;
+        const size_t vi = ek ? (size_t)(ek - 1u) * SE_BRICK_STRIDE + (size_t)(oxy + oz[zi]) : 0;
         const float v = m.vx[vi];
         V[zi][yi][xi] = ek ? v : fc.init_x;
       }
+    }
   f3 g;
   g.x = (((V[1][1][2] - V[1][1][0]) * (1 - fx) + (V[1][1][3] - V[1][1][1]) * fx) * (1 - fy) +
          ((V[1][2][2] - V[1][2][0]) * (1 - fx) + (V[1][2][3] - V[1][2][1]) * fx) * fy) * (1 - fz) +
