@@ -193,6 +193,8 @@ class DenseSLAMPipeline:
         keeps passing the same object; anything else is converted (and held) on every call."""
         if type(k) is int:
             return k
+        if isinstance(k, np.integer):
+            return int(k)
         if k is self._k_last:
             return self._k_addr
         if type(k) is np.ndarray and k.dtype == np.float32 and k.size == 4 and k.flags.c_contiguous:
@@ -281,7 +283,7 @@ class DenseSLAMPipeline:
         the caller, who keeps it alive -- the closed loop's per-frame Python cost is what the host adds to the frame); k likewise.
         Returns bit 0 = integrated, bit 1 = raycast."""
         if type(pose_cm) is not int:
-            pose_cm = self._addr(pose_cm, np.float32, 16)
+            pose_cm = int(pose_cm) if isinstance(pose_cm, np.integer) else self._addr(pose_cm, np.float32, 16)
         return self._check(self.lib.se_hip_frame(self._h, depth_ptr, pose_cm, self._k(k), integration_rate, mu, frame))
 
     def raycasting(self, k, mu: float, frame: int) -> bool:

@@ -165,7 +165,7 @@ def test_pipeline_passes_remembered_addresses():
     assert C.cast(p._k(k), C.POINTER(C.c_float))[0] == 500.0
     b = p._k([1.0, 2.0, 3.0, 4.0])
     assert b != a and [C.cast(b, C.POINTER(C.c_float))[i] for i in range(4)] == [1.0, 2.0, 3.0, 4.0]
-    assert p._k(k.astype(np.float64)) != a and p._k(k) == a and p._k(12345) == 12345
+    assert p._k(k.astype(np.float64)) != a and p._k(k) == a and p._k(12345) == 12345 and p._k(np.int64(12345)) == 12345
     # pyramid: the default is one shared array; others are converted and held
     assert p._pyr(None) == p._pyr((10, 5, 4)) == (DenseSLAMPipeline._PYRAMID_ADDR, 3)
     pa, n = p._pyr([4, 3])
