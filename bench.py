@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=20, help="timed frames of the CPU baseline sample")
     ap.add_argument("--cpu-reps", type=int, default=4, help="repetitions of the CPU baseline sample (the fastest is reported, all are listed)")
     ap.add_argument("--sustain", type=int, default=200, help="N = 1: after the K contract steps keep going until this many frames have been timed in total (0 = off)")
+    ap.add_argument("--no-streaming", action="store_true", help="N = 1: the eager two-queue schedule instead of the one-queue streaming schedule (se_hip_set_streaming)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU warm-up on a scratch map before the warm-up frames (see prewarm())")
     ap.add_argument("--shard-sweep", action="store_true", help="N > 1: owner-computes integration + brick all-gather instead of the replicated sweep (SURVEY 8e option 4; DESIGN.md section 7: measured slower, off by default)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the value_closed_loop leg (profiling runs: nothing behind the timed loop)")
@@ -288,7 +289,7 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
     run("closed_loop", True, False)
     run("tracking_on", True, True)
     nb = {512: 1 << 16, 1024: 1 << 19}.get(N, 1 << 21)
-    run("pooled", False, False, max_blocks=nb)
+    run("pooled", False, False, max_blocks=nb, streaming=not args.no_streaming)
     out["closed_loop"]["note"] = "per-frame se_hip_sync(); scan / sweep / raycast of a frame strictly in sequence"
     out["pooled"]["note"] = f"max_blocks = {nb}"
     return out
@@ -312,7 +313,7 @@ def stress_leg(args, field, device, n: int):
     ptrs = [dev[f].data_ptr() for f in range(warm + n)]
     out = {"stream": "ICL-like stress (supereight_amd/synthetic.py StressStream)", "frames": n, "warmup": warm}
     for label, sync in (("fps", False), ("closed_loop_fps", True)):
-        p = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=device)
+        p = DenseSLAMPipeline((W, H), N, dim, field_type=field, device=device, streaming=(not sync) and not args.no_streaming)
         _, scratch = prewarm(args, field, ptrs, poses, k32, device)
         pose_at, k_at = [DenseSLAMPipeline.addr(a) for a in pcm], DenseSLAMPipeline.addr(k32)
         for f in range(warm):
@@ -418,7 +419,7 @@ def main():
 
     # the pipeline is created BEFORE the pre-warm and the scratch map is freed AFTER the timed regions: allocating or
     # freeing gigabytes idles the GPU for tens of milliseconds, long enough for the clocks to drop again
-    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank, shard_sweep=args.shard_sweep)
+    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank, shard_sweep=args.shard_sweep, streaming=not args.no_streaming)
     prewarm_frames, scratch = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else (0, None)
 
     def barrier():
@@ -428,8 +429,13 @@ def main():
     freeze_gc()
     for f in range(warm):
         sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
+    # The timed window holds ALL the work of frames warm .. warm+K-1 and nothing else (se_apps/src/benchmark.cpp:148-152,166-167 brackets every
+    # frame's integration + raycasting): the raycast of frame warm-1, held back by the streaming schedule, is launched and finished HERE, before t0,
+    # and the raycast of frame warm+K-1 is launched and finished before t1 (sp.p.sync() does both: launch, then wait).  The launch counters read at t1
+    # prove it in the JSON line: K allocation scans, K sweeps, K raycasts.
+    sp.p.sync()    # (raises if a pool or key list overflowed during warm-up)
     torch.cuda.synchronize()
-    sp.p.counts()  # raises if a pool or key list overflowed during warm-up
+    sp.p.launch_counts(reset=True)
     # per-kernel HIP events on every stride-th contract step: each sampled frame costs 6 event records on the launch
     # streams (measured: every 2nd frame sampled lowers `value` by 9 %, every 5th by < 2 %), so at least 4 samples, not more
     stride = max(1, min(args.event_stride, K // 4 if K >= 4 else 1))
@@ -443,10 +449,15 @@ def main():
         sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
         if throttle and (f - warm) % throttle == throttle - 1:
             sp.p.sync()
+    sp.p.sync()                 # launches the held-back raycast of the last timed frame, then waits for the handle's streams
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    launched = sp.p.launch_counts(reset=True)
+    for kk in ("alloc_scan", "integrate", "raycast"):
+        if launched[kk] != K or launched["pending"]:
+            raise RuntimeError(f"timed region of {K} frames holds {launched}: every frame's scan, sweep and raycast must be inside it")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -457,9 +468,15 @@ def main():
         sp.p.enable_timing(False)                   # kernel events (and the roofline) belong to the K contract steps
         for f in range(warm + K, F):
             sp.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
+        sp.p.sync()
         torch.cuda.synchronize()
         t3 = time.perf_counter()
+        launched2 = sp.p.launch_counts(reset=True)
+        for kk in ("alloc_scan", "integrate", "raycast"):
+            if launched2[kk] != extra or launched2["pending"]:
+                raise RuntimeError(f"second timed region of {extra} frames holds {launched2}")
         sustained = {"frames": K + extra, "fps": (K + extra) / (elapsed + (t3 - t2)), "fps_second_region": extra / (t3 - t2),
+                     "launches_in_timed_regions": {kk: launched[kk] + launched2[kk] for kk in ("alloc_scan", "integrate", "raycast", "fused")},
                      "note": f"the K = {K} contract steps plus {extra} more frames of the same stream, two timed regions added up"}
     fused_schedule = world == 1 and sp.p.frame_is_fused()
     timings = sp.p.timings(reset=True) if not args.no_events else None
@@ -477,11 +494,12 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": warm,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
+            "launches_in_timed_region": {kk: launched[kk] for kk in ("alloc_scan", "integrate", "raycast", "fused")},
             "dtype": "f32", "data": "real (.raw)" if args.raw else "synthetic",
             "config": {"workload": f"{stream_name} {W}x{H} -> {N}^3 / {dim} m "
                                    f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
                                    f"GT poses, frames {warm}..{warm + K - 1} timed",
-                       "schedule": ("one queue: raycast(f) + scan(f+1) in one launch, sweep(f+1) behind it (se_hip_frame defers the raycast to the next call)" if fused_schedule
+                       "schedule": ("one queue: raycast(f) + scan(f+1) in one launch, sweep(f+1) behind it (se_hip_set_streaming: se_hip_frame holds a frame's raycast back until the next call)" if fused_schedule
                                     else "two queues: scan(f+1) on a side stream beside raycast(f), event wait in front of sweep(f+1)"),
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists" + (", sweep sharded by block owner + RCCL all-gather of the updated bricks" if sp.shard_sweep else ""),
                        "blocks_allocated": nblocks, "nodes_allocated": nnodes,
@@ -523,7 +541,7 @@ def main():
         # (2) untimed event replay: the same pipelined loop with HIP events on EVERY frame (the timed region above samples
         # every stride-th frame only, because events cost throughput there): per-kernel averages over each window
         replay = {}
-        ep = ShardedPipeline((W, H), N, dim, field, 0, 1, local_rank)
+        ep = ShardedPipeline((W, H), N, dim, field, 0, 1, local_rank, streaming=not args.no_streaming)
         for f in range(warm):
             ep.frame(depth_ptrs[f], poses_cm[f], k, mu, f)
         ep.p.sync()

@@ -74,6 +74,9 @@ class DenseSLAMSystem {
     c.field_type = is_sdf() ? SE_HIP_FIELD_SDF : SE_HIP_FIELD_OFUSION;
     c.device = config.hip_device; c.max_blocks = config.hip_max_blocks;
     if (se_hip_create(&c, &h_) != SE_HIP_OK) throw std::runtime_error(std::string("DenseSLAMSystem: ") + se_hip_last_error());
+    /* The class never hands out device pointers: every way an application can look at vertex_ / normal_ (tracking, render*, getVertexNormal)
+     * is an API call that launches a held-back raycast first, so the one-queue streaming schedule is safe by construction here. */
+    if (config.hip_streaming) se_hip_set_streaming(h_, 1);
     live().push_back(h_);
   }
   ~DenseSLAMSystem() {
@@ -96,6 +99,8 @@ class DenseSLAMSystem {
   }
   /* the reference's float_depth_ handed over directly (metres) */
   bool preprocessing(const float* depthMetres) { return ok(se_hip_upload_depth(h_, depthMetres)); }
+  /* ... or left where a device-side producer put it (HBM, metres, valid until the next call): no copy at all */
+  bool preprocessingDevice(const float* deviceDepthMetres) { return ok(se_hip_set_depth_device(h_, deviceDepthMetres)); }
 
   /* DenseSLAMSystem.h:173 / DenseSLAMSystem.cpp:143-189: ICP against the last raycast, on the device */
   bool tracking(const Eigen::Vector4f& k, float icp_threshold, unsigned tracking_rate, unsigned frame) {
@@ -114,7 +119,8 @@ class DenseSLAMSystem {
   }
   /* DenseSLAMSystem.h:212 / DenseSLAMSystem.cpp:191-204 */
   bool raycasting(const Eigen::Vector4f& k, float mu, unsigned int frame) {
-    const int r = se_hip_raycast(h_, pose_.data(), k.data(), mu, frame);
+    /* held back until the next integration()'s allocation scan (one launch for both) on a streaming handle, se_hip_raycast otherwise */
+    const int r = se_hip_raycast_deferred(h_, pose_.data(), k.data(), mu, frame);
     ok(r);
     if (r > 0) raycast_pose_ = pose_;
     return r > 0;

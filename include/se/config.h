@@ -3,8 +3,8 @@
  *   se_denseslam/include/se/config.h:39-214
  * so that an application that fills it (se_apps/include/default_parameters.h:200-260 does, from the command line)
  * compiles unchanged against this build.  Same names, types and order; the Eigen types are the real ones when
- * <Eigen/Dense> is installed and the PODs of se/DenseSLAMSystem.h otherwise.  Two fields are appended for this build
- * (both default to "as the reference": device 0, automatic brick layout).
+ * <Eigen/Dense> is installed and the PODs of se/DenseSLAMSystem.h otherwise.  Three fields are appended for this build
+ * (device 0, automatic brick layout, the streaming schedule that changes no observable result).
  */
 #ifndef SE_HIP_CONFIG_H
 #define SE_HIP_CONFIG_H
@@ -45,6 +45,8 @@ struct Configuration {
   /* ---- additions of this build (not in the reference) */
   int hip_device = 0;                  /* HIP device ordinal of the map */
   long long hip_max_blocks = 0;        /* > 0: pooled bricks with this capacity instead of the dense brick grid */
+  bool hip_streaming = true;           /* raycasting() may be launched together with the next integration()'s allocation scan (se_hip_set_streaming);
+                                          nothing an application can observe through DenseSLAMSystem changes */
 };
 
 #endif /* SE_HIP_CONFIG_H */

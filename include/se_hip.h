@@ -94,11 +94,31 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
  * stream is idle at the call (a caller that synchronises every frame) gets the scan straight onto the main stream, and
  * nobody else consumes its list.  se_hip_alloc_exchange / se_hip_alloc_commit follow the stream the last scan ran on. */
 int se_hip_scan_overlaps(se_hip_pipeline* p);
-/* 1 if se_hip_frame runs the one-queue streaming schedule on this handle (r04): the raycast of a frame is deferred to the next se_hip_frame call,
- * which launches it together with that frame's allocation scan as one kernel on the main stream; any other entry point launches a deferred raycast
- * first, so nothing a caller can read is ever stale.  Plain single-device handles with images of up to 2 560 raycast workgroups (640x480) only;
- * SE_HIP_FUSE=0 switches it off.  Does not itself launch the deferred raycast. */
+/* ---- streaming callers: the one-queue schedule (off by default).
+ * The reference's loop is integration(f); raycasting(f); integration(f+1); ... (se_apps/src/benchmark.cpp:148-167).  A caller that streams frames
+ * without looking at each frame's vertex_ / normal_ can have raycasting(f) and the allocation scan of integration(f+1) run as ONE launch on the
+ * handle's stream: with se_hip_set_streaming(p, 1), se_hip_frame and se_hip_raycast_deferred do not enqueue the raycast of a frame but hold it back
+ * until the next se_hip_integrate / se_hip_frame, which launches it together with that frame's scan.  ANY other entry point of this header
+ * (se_hip_sync, the image getters, se_hip_raycast, se_hip_track, the render calls, ...; not: the depth uploads, se_hip_filter_depth,
+ * se_hip_enable_timing, se_hip_get_launch_counts) launches an outstanding raycast first, so whatever is read THROUGH the API is what the eager
+ * schedule gives.  Reading past the API is what the mode cannot make safe: a caller kernel ordered on the handle's stream behind se_hip_frame(f)
+ * would find frame f-1's images.  Therefore
+ *   - the mode is opt-in (off: se_hip_frame == se_hip_set_depth_device + se_hip_integrate + se_hip_raycast, all enqueued when it returns);
+ *   - se_hip_vertex_normal_device on a streaming handle WITHOUT an image ring switches deferral off for good (sticky): raw pointers and deferral
+ *     never coexist;
+ *   - with an image ring (below) the contract is explicit: slot (f % slots) holds frame f's images once the NEXT se_hip_frame / se_hip_integrate
+ *     call (or any flushing call) has returned and the handle's stream has reached that point.
+ * Plain single-device handles whose raycast fits the chip in one round of workgroups (640x480: 2 400 of 2 560) fuse; others (row-sharded, exchange
+ * set, caller key buffer, statistics on, larger images) keep the eager two-queue schedule whatever the flag says.
+ * se_hip_set_streaming returns 1 if the handle will fuse, 0 if not (or off); se_hip_frame_is_fused reports the same without changing anything. */
+int se_hip_set_streaming(se_hip_pipeline* p, int32_t on);
 int se_hip_frame_is_fused(se_hip_pipeline* p);
+/* vertex_ / normal_ into a caller-owned device ring instead of the handle's own images: the raycast of frame f -- eager, deferred or fused --
+ * writes slot f % slots, a slot = [vertex: width*height*3 floats][normal: width*height*3 floats] (se_hip_image_tile_bytes(p, height) bytes), and
+ * that slot IS vertex_ / normal_ for every later consumer (se_hip_track, the render calls, the getters) until the next raycast.  This is how a
+ * streaming caller keeps every frame's images (tests/test_gpu_stress_parity.py compares each slot of a fused stream with the oracle).
+ * NULL, 0 restores the handle's own images (the current images are copied back; synchronises). */
+int se_hip_set_image_ring(se_hip_pipeline* p, float* device_ring, int32_t slots);
 
 /* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by
  * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141). */
@@ -177,19 +197,24 @@ int se_hip_gather_images(se_hip_pipeline* p, void* send_device, void* recv_devic
 
 /* One frame of the loop of se_apps/src/benchmark.cpp:148-167 in one call: hand-over of a device-resident float_depth_
  * (NULL = keep the current depth image), then integration(), then raycasting() with the same pose -- exactly
- * se_hip_set_depth_device + se_hip_integrate + se_hip_raycast.  Returns bit 0 = integration ran, bit 1 = raycasting ran.
- * r04: on a handle for which se_hip_frame_is_fused() is 1 the raycast is ENQUEUED LATER -- together with the next se_hip_frame call's allocation scan,
- * as one kernel -- or by the next call of any other entry point of this header (se_hip_sync, the image getters, se_hip_track, ...), whichever
- * comes first; what a caller can observe is unchanged.  The depth image handed over must stay valid until the next call (it always had to:
- * the scan reads it asynchronously). */
+ * se_hip_set_depth_device + se_hip_integrate + se_hip_raycast (se_hip_raycast_deferred on a streaming handle, see se_hip_set_streaming).
+ * Returns bit 0 = integration ran, bit 1 = raycasting ran (or is held back).  The depth image handed over must stay valid until the next
+ * call (the scan and the sweep read it asynchronously). */
 int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t integration_rate,
                  float mu, uint32_t frame);
 
 /* ---- bool DenseSLAMSystem::raycasting(const Vector4f& k, float mu, unsigned frame)
  *      (DenseSLAMSystem.h:212, DenseSLAMSystem.cpp:191-204) -> vertex_, normal_ */
 int se_hip_raycast(se_hip_pipeline* p, const float pose[16], const float k[4], float mu, uint32_t frame);
+/* raycasting() of a streaming caller (se_hip_set_streaming): same gate, same result, but the launch is held back until the next
+ * se_hip_integrate / se_hip_frame (one launch with that frame's allocation scan) or any flushing call; on a handle that does not fuse it IS
+ * se_hip_raycast.  include/se/DenseSLAMSystem.h's raycasting() calls this one. */
+int se_hip_raycast_deferred(se_hip_pipeline* p, const float pose[16], const float k[4], float mu, uint32_t frame);
 /* vertex_ / normal_ : se::Image<Eigen::Vector3f>, packed 12 bytes per pixel, world frame */
 int se_hip_download_vertex_normal(se_hip_pipeline* p, float* host_vertex_xyz, float* host_normal_xyz);
+/* The device images themselves (zero-copy consumers).  They are current when the call returns (an outstanding deferred raycast is launched first)
+ * and are rewritten by the next raycast on the handle's stream.  On a streaming handle without an image ring the call ends deferral for good
+ * (see se_hip_set_streaming); with a ring it returns the slot of the last raycast. */
 int se_hip_vertex_normal_device(se_hip_pipeline* p, float** device_vertex_xyz, float** device_normal_xyz);
 
 /* ---- "next" row f-2: bool DenseSLAMSystem::tracking(const Vector4f& k, float icp_threshold,
@@ -281,6 +306,11 @@ int se_hip_dump_mesh(se_hip_pipeline* p, const char* filename);
 int se_hip_enable_timing(se_hip_pipeline* p, int32_t on);
 /* sum of launch durations [ms] and number of launches per kernel since the last reset */
 int se_hip_get_timings(se_hip_pipeline* p, double ms_sum[SE_HIP_K_COUNT], int64_t launches[SE_HIP_K_COUNT], int32_t reset);
+/* Kernel launches per kind since the last reset, counted on the host at enqueue time (no events, no synchronisation, does not flush a deferred
+ * raycast): counts[SE_HIP_K_*], and counts[SE_HIP_K_COUNT] = launches that were the fused raycast + scan kernel (each of which also counts as one
+ * raycast and one allocation scan).  Returns 1 if a deferred raycast is outstanding, else 0.  bench.py asserts with it that a timed region of K
+ * frames holds K scans, K sweeps and K raycasts. */
+int se_hip_get_launch_counts(se_hip_pipeline* p, int64_t counts[SE_HIP_K_COUNT + 1], int32_t reset);
 /* Work counters behind the algorithmic-bytes figures of the roofline (instrumented kernel
  * variants, slower; off by default): out[0..7] = alloc probes, new keys, swept blocks, nodes,
  * get calls, interp calls, grad calls, ray hits -- accumulated since enabled / last read;

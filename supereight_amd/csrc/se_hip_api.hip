@@ -110,10 +110,12 @@ struct se_hip_pipeline {
   bool gate_armed = false;         // a sweep was enqueued that no scan / upload has waited for yet
   bool gate_followed = false;      // ... and a raycast was enqueued behind it
   bool sharded = false;        // this replica scans / raycasts a row range of the image (multi-GPU)
-  // r04, one queue for streaming callers: se_hip_frame defers a frame's raycast to the next se_hip_frame call, which launches it together with that
-  // frame's allocation scan as ONE kernel on the main stream (k_raycast_scan) -- no second queue, no wait in front of the sweep.  Any other API
-  // call launches the deferred raycast first (check()), so results are always in place when somebody looks.  SE_HIP_FUSE=0: off.
-  bool fuse = true, in_frame = false, has_pending = false;
+  // One queue for streaming callers (se_hip_set_streaming, off by default): se_hip_frame / se_hip_raycast_deferred defer a frame's raycast to the next
+  // frame's allocation scan, which launches it in ONE kernel with that scan on the main stream (k_raycast_scan) -- no second queue, no wait in front of
+  // the sweep.  Any other API call launches the deferred raycast first (check()), so results are always in place when somebody looks through the API;
+  // a caller that was handed the raw image pointers (se_hip_vertex_normal_device, no image ring) could look past the API: that switches deferral off for good.
+  bool fuse = false, in_frame = false, has_pending = false;
+  bool ptrs_exposed = false;   // sticky: se_hip_vertex_normal_device handed out vertex_ / normal_ of a handle without an image ring
   float pend_pose[16] = {0}, pend_k[4] = {0}, pend_mu = 0.f;
   uint32_t pend_frame = 0;
   bool images_complete = true; // vertex_ / normal_ hold every row of the last raycast (a row-sharded replica: only after se_hip_apply_image_tiles / se_hip_gather_images)
@@ -168,8 +170,13 @@ struct se_hip_pipeline {
   bool stage_used[kStage] = {false, false, false};
   size_t stage_cap = 0;
   int stage_next = 0;
-  float* vertex = nullptr;
-  float* normal = nullptr;
+  float* vertex = nullptr;       // vertex_ / normal_ as every consumer (tracking, rendering, the getters) sees them: the images of the LAST raycast
+  float* normal = nullptr;       // launched -- the handle's own buffers, or the slot of the image ring that raycast wrote
+  float* vertex_own = nullptr;
+  float* normal_own = nullptr;
+  float* ring = nullptr;         // se_hip_set_image_ring: slot s = [vertex W*H*3 floats][normal W*H*3 floats] at ring + s * 2 * W*H*3
+  int ring_slots = 0;
+  int64_t n_launch[SE_HIP_K_COUNT + 1] = {0};   // kernel launches per kind since the last reset, counted on the host (no events needed); [SE_HIP_K_COUNT] = fused
   float* bspline = nullptr;
   float* logodds = nullptr;
   unsigned long long* chain = nullptr;  // 3 candidates for the keys[0] quirk
@@ -213,6 +220,7 @@ hipEvent_t get_event(se_hip_pipeline* p) {
 struct ScopedTimer {
   se_hip_pipeline* p; int k; hipStream_t s; hipEvent_t a{}, b{};
   ScopedTimer(se_hip_pipeline* p_, int k_, hipStream_t s_ = nullptr) : p(p_), k(k_), s(s_ ? s_ : p_->stream) {
+    p->n_launch[k]++;
     if (p->timing) { a = get_event(p); b = get_event(p); hipEventRecord(a, s); }
   }
   ~ScopedTimer() {
@@ -405,6 +413,19 @@ int check_overflow(se_hip_pipeline* p) {
   return SE_HIP_OK;
 }
 
+// the images the raycast of `frame` writes, and every consumer (tracking, rendering, the getters) reads from then on
+void select_image_target(se_hip_pipeline* p, uint32_t frame) {
+  if (p->ring) {
+    const size_t n3 = (size_t)p->cfg.width * p->cfg.height * 3;
+    p->vertex = p->ring + (size_t)(frame % (uint32_t)p->ring_slots) * 2 * n3;
+    p->normal = p->vertex + n3;
+  } else {
+    p->vertex = p->vertex_own; p->normal = p->normal_own;
+  }
+}
+// scope of an entry point that may run with a deferred raycast outstanding (check() then leaves it alone)
+struct InFrame { se_hip_pipeline* p; bool was; explicit InFrame(se_hip_pipeline* q) : p(q), was(q->in_frame) { q->in_frame = true; } ~InFrame() { p->in_frame = was; } };
+
 bool stage_runs_integration(uint32_t frame, uint32_t rate) { return ((frame % rate) == 0) || (frame <= 3); }
 
 // Octree::init (se_core/include/se/octree.hpp:425-437) on the device: empty index, root node, every brick and node value
@@ -472,7 +493,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
   if (const char* ev = std::getenv("SE_HIP_OF_SCAN_TILED")) p->of_scan_tiled = std::atoi(ev) != 0;   // A/B knob
-  if (const char* ev = std::getenv("SE_HIP_FUSE")) p->fuse = std::atoi(ev) != 0;                     // A/B knob (one-queue streaming schedule)
   if (const char* ev = std::getenv("SE_HIP_ICP_LOOKAHEAD")) p->icp_lookahead = std::max(0, std::atoi(ev));   // A/B knob (0: every ICP iteration enqueued up front)
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
 #ifdef SE_DIAG
@@ -569,8 +589,9 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->newkeys_own = m.newkeys; p->cap_keys_own = m.cap_keys;
   ALLOC(p->newkeys_own2, (m.cap_keys + 1) * sizeof(unsigned long long));
   ALLOC(p->depth_own, (size_t)cfg->width * cfg->height * sizeof(float));
-  ALLOC(p->vertex, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
-  ALLOC(p->normal, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
+  ALLOC(p->vertex_own, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
+  ALLOC(p->normal_own, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
+  p->vertex = p->vertex_own; p->normal = p->normal_own;
   ALLOC(p->chain, 4 * sizeof(unsigned long long));
   const size_t n_tiles = ((size_t)(cfg->width + SE_TILE_W - 1) / SE_TILE_W) * ((size_t)(cfg->height + SE_TILE_H - 1) / SE_TILE_H);
   ALLOC(p->tile_cost, (n_tiles + 4096) * sizeof(unsigned short));   // (+ padding: se_ray_schedule reads it in 16-byte pieces)
@@ -624,7 +645,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
   void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.bsat, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
-                  p->depth_own, p->depth_mm, p->vertex, p->normal, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
+                  p->depth_own, p->depth_mm, p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
   for (auto* q : p->pyr_vertex) if (q) hipFree(q);
@@ -727,6 +748,8 @@ int staged_upload(se_hip_pipeline* p, void* dev, const void* host, size_t bytes,
 }
 
 int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  InFrame guard(p);   // (a deferred raycast reads the map, not the depth image: the next frame's input may arrive before it is launched)
   if (int r = check(p)) return r;
   if (!host_depth_m) return fail(SE_HIP_E_INVALID, "null depth");
   hipStream_t s = upload_stream(p);
@@ -737,6 +760,8 @@ int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m) {
 }
 
 int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t in_w, int32_t in_h) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  InFrame guard(p);
   if (int r = check(p)) return r;
   if (!host_mm) return fail(SE_HIP_E_INVALID, "null depth");
   const int W = p->cfg.width, H = p->cfg.height;
@@ -759,6 +784,8 @@ int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t 
 }
 
 int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  InFrame guard(p);
   if (int r = check(p)) return r;
   p->depth = device_depth_m ? device_depth_m : p->depth_own;
   return SE_HIP_OK;
@@ -771,6 +798,8 @@ int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& s
   if (int r = check_overflow(p)) return r;
   std::memcpy(p->raycast_pose, p->pend_pose, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   p->images_complete = true;
+  select_image_target(p, p->pend_frame);
+  p->n_launch[SE_HIP_K_ALLOC_SCAN]++; p->n_launch[SE_HIP_K_COUNT]++;   // (the raycast half is counted by the timer scope below)
   RayLaunchArgs L = make_ray_args(p, p->pend_pose, p->pend_k, p->pend_mu);
   if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
   const RayArgs& a = L.a;
@@ -1140,62 +1169,94 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   return 1;
 }
 
-int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
-  int r = se_hip_alloc_scan(p, pose, k, rate, mu, frame);
-  if (r <= 0) return r;
-  return se_hip_integrate_sweep(p, pose, k, rate, mu, frame);
-}
-
-// One frame of the hot path in one call: float_depth_ hand-over (device pointer) + integration() + raycasting().
-// The same three calls a host makes per frame, without crossing the FFI three times (ctypes: ~5 us each).
-// r04: when the handle is a plain single-device pipeline (own key lists, no row shard, no exchange, no statistics) the raycast is not launched
-// here but DEFERRED: the next se_hip_frame call launches it in one kernel with that frame's allocation scan (launch_raycast_scan), and any other
-// API call launches it first (check()), so a caller that looks at a frame's images, synchronises or tracks sees exactly what it saw before -- only a
-// caller that streams frames back to back gets the one-queue schedule.
+// The one-queue streaming schedule (se_hip_set_streaming): a frame's raycast is not launched by se_hip_frame / se_hip_raycast_deferred but held back
+// until the next frame's allocation scan, which takes it along in one launch (launch_raycast_scan); any other API call launches it first (check()), so a
+// caller that looks at a frame's images through the API, synchronises or tracks sees exactly what the eager schedule shows.  Plain single-device handles
+// only, and only while the raycast's workgroups fit the chip in one round -- 640x480: 2 400 of 2 560 --: in a launch of several rounds the scan's
+// workgroups inherit the raycast's register and LDS footprint and no longer slip into the gaps (1280x960 -> 2048^3: 356 us fused against 285 us side by
+// side, profiles/r04p_march_skip_ab.log), so larger images keep the two-queue schedule.
 static bool frame_can_fuse(se_hip_pipeline* p) {
   const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
   const int ray_pairs = (((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H) + 1) / 2;
-  return p->fuse && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
+  return p->fuse && !p->ptrs_exposed && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
+}
+int se_hip_set_streaming(se_hip_pipeline* p, int32_t on) {
+  if (int r = check(p)) return r;   // (switching off launches an outstanding raycast first)
+  p->fuse = on != 0;
+  return frame_can_fuse(p) ? 1 : 0;
 }
 int se_hip_frame_is_fused(se_hip_pipeline* p) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
   return frame_can_fuse(p) ? 1 : 0;
 }
+int se_hip_set_image_ring(se_hip_pipeline* p, float* device_ring, int32_t slots) {
+  if (int r = check(p)) return r;
+  if ((device_ring != nullptr) != (slots > 0)) return fail(SE_HIP_E_INVALID, "bad argument (ring and slots go together)");
+  p->ring = device_ring; p->ring_slots = device_ring ? slots : 0;
+  if (!device_ring) {
+    // vertex_ / normal_ stay what they were: the last raycast's images move back into the handle's own buffers
+    const size_t bytes = (size_t)p->cfg.width * p->cfg.height * 3 * sizeof(float);
+    if (p->vertex != p->vertex_own) {
+      HIP_TRY(hipMemcpyAsync(p->vertex_own, p->vertex, bytes, hipMemcpyDeviceToDevice, p->stream));
+      HIP_TRY(hipMemcpyAsync(p->normal_own, p->normal, bytes, hipMemcpyDeviceToDevice, p->stream));
+      HIP_TRY(hipStreamSynchronize(p->stream));   // (the caller may free the ring when this returns)
+    }
+    p->vertex = p->vertex_own; p->normal = p->normal_own;
+  }
+  return SE_HIP_OK;
+}
 extern "C++" int flush_pending_raycast(se_hip_pipeline* p) {
   if (!p->has_pending) return SE_HIP_OK;
   p->has_pending = false;
-  const bool was = p->in_frame;
-  p->in_frame = true;      // (the nested check() must not recurse)
+  InFrame guard(p);      // (the nested check() must not recurse)
   const int r = se_hip_raycast(p, p->pend_pose, p->pend_k, p->pend_mu, p->pend_frame);
-  p->in_frame = was;
   return r < 0 ? r : SE_HIP_OK;
 }
-int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+
+int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
-  struct InFrame { se_hip_pipeline* p; bool was; InFrame(se_hip_pipeline* q) : p(q), was(q->in_frame) { q->in_frame = true; } ~InFrame() { p->in_frame = was; } } guard(p);
+  InFrame guard(p);
   if (int r = check(p)) return r;
   if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
-  // (only while the raycast's workgroups fit the chip in one round -- 640x480: 2 400 of 2 560 --: in a launch of several rounds the scan's workgroups
-  // inherit the raycast's register and LDS footprint and no longer slip into the gaps -- 1280x960 -> 2048^3: 356 us fused against 285 us side by side,
-  // 841 vs 883 frames/s (profiles/r04p_march_skip_ab.log) -- so larger images keep the two-queue schedule)
-  const bool can_fuse = frame_can_fuse(p);
   // a deferred raycast must run before this frame's sweep: together with this frame's scan if there is one, else on its own, now
-  if (p->has_pending && !(can_fuse && stage_runs_integration(frame, rate))) { if (int r = flush_pending_raycast(p)) return r; }
+  if (p->has_pending && !(frame_can_fuse(p) && stage_runs_integration(frame, rate))) { if (int r = flush_pending_raycast(p)) return r; }
+  int r = se_hip_alloc_scan(p, pose, k, rate, mu, frame);
+  if (p->has_pending) { if (int q = flush_pending_raycast(p)) return q; }   // (cannot happen: a scan that ran took it along)
+  if (r <= 0) return r;
+  return se_hip_integrate_sweep(p, pose, k, rate, mu, frame);
+}
+
+// raycasting() of a streaming caller: launched with the next frame's allocation scan (or by whatever call comes first)
+int se_hip_raycast_deferred(se_hip_pipeline* p, const float pose[16], const float k[4], float mu, uint32_t frame) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  InFrame guard(p);
+  if (int r = check(p)) return r;
+  if (!pose || !k) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (p->has_pending) { if (int r = flush_pending_raycast(p)) return r; }   // two raycasts without an integration between them
+  if (!(frame > 2)) return 0;      // DenseSLAMSystem.cpp:195
+  if (!frame_can_fuse(p)) return se_hip_raycast(p, pose, k, mu, frame);
+  if (int r = check_overflow(p)) return r;
+  std::memcpy(p->pend_pose, pose, sizeof p->pend_pose); std::memcpy(p->pend_k, k, sizeof p->pend_k);
+  p->pend_mu = mu; p->pend_frame = frame; p->has_pending = true;
+  return 1;
+}
+
+// One frame of the hot path in one call: float_depth_ hand-over (device pointer) + integration() + raycasting().
+// The same three calls a host makes per frame, without crossing the FFI three times (ctypes: ~5 us each).
+int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float pose[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  InFrame guard(p);
+  if (int r = check(p)) return r;
+  if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (device_depth_m) p->depth = device_depth_m;
   int ran = 0;
   int r = se_hip_integrate(p, pose, k, rate, mu, frame);
   if (r < 0) return r;
   ran |= r > 0 ? 1 : 0;
-  if (p->has_pending) { if (int q = flush_pending_raycast(p)) return q; }   // (cannot happen: the scan above took it along)
-  if (can_fuse && frame > 2) {     // DenseSLAMSystem.cpp:195
-    std::memcpy(p->pend_pose, pose, sizeof p->pend_pose); std::memcpy(p->pend_k, k, sizeof p->pend_k);
-    p->pend_mu = mu; p->pend_frame = frame; p->has_pending = true;
-    return ran | 2;
-  }
-  r = se_hip_raycast(p, pose, k, mu, frame);
+  r = se_hip_raycast_deferred(p, pose, k, mu, frame);
   if (r < 0) return r;
   ran |= r > 0 ? 2 : 0;
-  return ran;   // bit 0: integration ran, bit 1: raycasting ran
+  return ran;   // bit 0: integration ran, bit 1: raycasting ran (or is deferred)
 }
 
 // ------------------------------------------------------------------------------------ raycast
@@ -1207,6 +1268,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   if (int r = join_scan(p)) return r;
   std::memcpy(p->raycast_pose, pose_cm, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   p->images_complete = !p->sharded;   // a row-sharded replica has just overwritten its own rows only
+  select_image_target(p, frame);
   const DevMap& m = p->map;
   RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
   if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
@@ -1292,6 +1354,10 @@ int se_hip_download_vertex_normal(se_hip_pipeline* p, float* v, float* n) {
 
 int se_hip_vertex_normal_device(se_hip_pipeline* p, float** v, float** n) {
   if (int r = check(p)) return r;
+  // Whoever holds these pointers can read the images without going through the API (its own kernel ordered on the handle's stream): with the raycast
+  // of a frame deferred it would see the previous frame's.  So the hand-out ends deferral on this handle for good -- unless the images go into a ring
+  // the caller supplied, whose contract (se_hip_set_image_ring) says when a slot is complete.
+  if (!p->ring) p->ptrs_exposed = true;
   if (v) *v = p->vertex;
   if (n) *n = p->normal;
   return SE_HIP_OK;
@@ -1458,7 +1524,7 @@ int se_hip_frame_tracked(se_hip_pipeline* p, const float* device_depth_m, const 
 }
 
 int se_hip_filter_depth(se_hip_pipeline* p, int32_t on) {
-  if (int r = check(p)) return r;
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");   // (a flag only: does not launch a deferred raycast)
   p->filter_input = on != 0;
   return SE_HIP_OK;
 }
@@ -1896,6 +1962,15 @@ int se_hip_get_timings(se_hip_pipeline* p, double ms_sum[SE_HIP_K_COUNT], int64_
     if (reset) { p->ms_sum[i] = 0; p->launches[i] = 0; }
   }
   return SE_HIP_OK;
+}
+
+int se_hip_get_launch_counts(se_hip_pipeline* p, int64_t counts[SE_HIP_K_COUNT + 1], int32_t reset) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");   // (host counters only: does not launch a deferred raycast)
+  for (int i = 0; i <= SE_HIP_K_COUNT; ++i) {
+    if (counts) counts[i] = p->n_launch[i];
+    if (reset) p->n_launch[i] = 0;
+  }
+  return p->has_pending ? 1 : 0;
 }
 
 int se_hip_enable_stats(se_hip_pipeline* p, int32_t on) {

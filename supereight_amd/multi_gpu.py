@@ -104,7 +104,7 @@ class ShardedPipeline:
 
     def __init__(self, input_size, volume_resolution, volume_dimension, field_type, rank, world, device,
                  small_words: int = 0, big_words: int = 0, max_blocks: int = 0, group=None,
-                 exchange_always: bool = False, shard_sweep: bool = False, brick_cap: int = 0):
+                 exchange_always: bool = False, shard_sweep: bool = False, brick_cap: int = 0, streaming: bool = False):
         import torch
         from .pipeline import DenseSLAMPipeline
         self.torch = torch
@@ -151,6 +151,8 @@ class ShardedPipeline:
             self._pg = pg if (not self.gloo and hasattr(pg, "_allgather_base")) else None
             self.direct = (not self.gloo) and self._direct_rccl(pg, dev)
         self.p.set_stream(self.main.cuda_stream)
+        if streaming and not self.exchange:
+            self.p.set_streaming(True)    # single replica streaming frames: the one-queue schedule (include/se_hip.h, se_hip_set_streaming)
         # Sharded sweep (SURVEY 8e option 4; off by default, DESIGN.md section 7 has the price): owner-computes integration
         # + an all-gather of the updated bricks instead of every replica sweeping every block.
         self.shard_sweep = bool(shard_sweep) and world > 1

@@ -49,6 +49,10 @@ EXPORTS = {
     "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_scan_overlaps": (C.c_int, [C.c_void_p]),
     "se_hip_frame_is_fused": (C.c_int, [C.c_void_p]),
+    "se_hip_set_streaming": (C.c_int, [C.c_void_p, C.c_int32]),
+    "se_hip_set_image_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "se_hip_raycast_deferred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]),
+    "se_hip_get_launch_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "se_hip_upload_depth": (C.c_int, [C.c_void_p, _f32p]),
     "se_hip_upload_depth_mm": (C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     "se_hip_set_depth_device": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -153,7 +157,7 @@ class DenseSLAMPipeline:
     _k_addr = 0
 
     def __init__(self, input_size, volume_resolution: int, volume_dimension: float, init_pose=None,
-                 field_type: int = SDF, device: int = 0, max_blocks: int = 0, rows=None):
+                 field_type: int = SDF, device: int = 0, max_blocks: int = 0, rows=None, streaming: bool = False):
         self.lib = load_library()
         self.W, self.H = int(input_size[0]), int(input_size[1])
         self.size, self.dim, self.field = int(volume_resolution), float(volume_dimension), field_type
@@ -165,6 +169,9 @@ class DenseSLAMPipeline:
         self._h = h
         self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else init_pose
         self._keepalive = None
+        self._ring_keepalive = None
+        if streaming:
+            self.set_streaming(True)
 
     # pose_ (camera -> world, row-major 4x4) and its column-major copy for the C ABI; assign, do not
     # modify in place
@@ -246,6 +253,25 @@ class DenseSLAMPipeline:
         """True if frame() runs the one-queue streaming schedule (deferred raycast + next frame's scan in one launch, include/se_hip.h)."""
         return bool(self._check(self.lib.se_hip_frame_is_fused(self._h)))
 
+    def set_streaming(self, on: bool = True) -> bool:
+        """Opt into the one-queue streaming schedule (se_hip_set_streaming): frame() / raycasting_deferred() hold a frame's raycast back until the
+        next frame's allocation scan.  Returns True if this handle will actually fuse."""
+        return bool(self._check(self.lib.se_hip_set_streaming(self._h, int(on))))
+
+    def set_image_ring(self, ptr: int, slots: int, keepalive=None):
+        """vertex_ / normal_ of frame f go to slot f % slots of a caller-owned device ring (se_hip_set_image_ring); ptr = 0 restores the own images."""
+        self._check(self.lib.se_hip_set_image_ring(self._h, C.c_void_p(ptr), slots))
+        self._ring_keepalive = keepalive
+
+    def launch_counts(self, reset: bool = False) -> dict:
+        """Kernel launches per kind since the last reset, counted at enqueue time (does not flush a deferred raycast); 'pending' = a raycast is held back."""
+        n = (C.c_int64 * (len(KERNELS) + 1))()
+        pend = self._check(self.lib.se_hip_get_launch_counts(self._h, n, int(reset)))
+        out = {k: int(n[i]) for i, k in enumerate(KERNELS)}
+        out["fused"] = int(n[len(KERNELS)])
+        out["pending"] = bool(pend)
+        return out
+
     def set_scan_stream(self, hip_stream_ptr: int):
         self._check(self.lib.se_hip_set_scan_stream(self._h, C.c_void_p(hip_stream_ptr)))
 
@@ -288,6 +314,10 @@ class DenseSLAMPipeline:
 
     def raycasting(self, k, mu: float, frame: int) -> bool:
         return bool(self._check(self.lib.se_hip_raycast(self._h, self._pose_cm_addr, self._k(k), mu, frame)))
+
+    def raycasting_deferred(self, k, mu: float, frame: int) -> bool:
+        """raycasting() of a streaming caller: on a handle that fuses, launched together with the next integration()'s allocation scan."""
+        return bool(self._check(self.lib.se_hip_raycast_deferred(self._h, self._pose_cm_addr, self._k(k), mu, frame)))
 
     def mesh(self) -> np.ndarray:
         """Marching-cubes triangles of the map, (n, 3, 3) float32 vertices in metres (order unspecified)."""

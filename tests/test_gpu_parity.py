@@ -99,13 +99,15 @@ def test_mm2meters_fused_upload():
     b.close()
 
 
+@pytest.mark.parametrize("streaming", [False, True], ids=["two-queue", "one-queue"])
 @pytest.mark.parametrize("field,W,H,N,dim,mu,frames", [(SDF, 320, 240, 512, 4.8, 0.1, 14), (OFUSION, 160, 120, 256, 2.4, 0.02, 10)], ids=["sdf", "ofusion"])
-def test_pipelined_stream_parity(field, W, H, N, dim, mu, frames):
+def test_pipelined_stream_parity(field, W, H, N, dim, mu, frames, streaming):
     """The parity cases above download the raycast after every frame, i.e. they synchronise, and a synchronised caller gets
     the serial schedule (scan on the main stream).  Here the frames are enqueued back to back from device-resident depth
-    images, as bench.py does: the allocation scan of frame f+1 runs on the scan stream beside the raycast of frame f, released
-    by the host gate, the two key lists alternate, the occupancy bits are published by the sweep.  The final map and the
-    last raycast must still be the oracle's, bit for bit."""
+    images, as bench.py does: the allocation scan of frame f+1 runs beside the raycast of frame f -- on the scan stream, released
+    by the host gate (two-queue), or in the same launch (one-queue, se_hip_set_streaming) --, the two key lists alternate, the
+    occupancy bits are published by the sweep.  The final map and the last raycast must still be the oracle's, bit for bit
+    (every frame's raycast of such a stream: tests/test_gpu_stress_parity.py::test_stress_stream_pipelined)."""
     import torch
     from oracle.binding import OraclePipeline
     from supereight_amd.pipeline import DenseSLAMPipeline
@@ -114,11 +116,12 @@ def test_pipelined_stream_parity(field, W, H, N, dim, mu, frames):
     depths = [s.depth(f) for f in range(frames)]
     poses = [s.pose(f) for f in range(frames)]
     dev = torch.from_numpy(np.stack(depths)).cuda()
-    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field)
-    assert gpu.scan_overlaps()
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field, streaming=streaming)
+    assert gpu.scan_overlaps() and gpu.frame_is_fused() == streaming
     k = np.ascontiguousarray(s.k, np.float32)
     for f in range(frames):
         gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)       # no synchronisation between frames
+    assert gpu.launch_counts()["fused"] == (frames - 4 if streaming else 0)
     cpu = OraclePipeline(field, N, dim, W, H)
     for f in range(frames):
         cpu.integrate(depths[f], poses[f], s.k, mu, f)
@@ -135,10 +138,9 @@ def test_pipelined_stream_parity(field, W, H, N, dim, mu, frames):
 
 @pytest.mark.parametrize("max_blocks", [0, 1 << 13], ids=["dense", "pooled"])
 def test_weight_saturated_blocks_stay_bit_exact(max_blocks):
-    """r04: once all 512 weights of an SDF block have reached maxweight (100 observations), the sweep neither reads nor writes its y
-    plane any more (k_integrate, `bsat`).  120 frames of the slow room stream -- every block in view from frame 0 saturates at
-    frame 99 -- against the oracle: maps after frames 99, 100, 101 and 119 and the raycast of the last frame, bit for bit; the run
-    must actually contain saturated blocks."""
+    """Weights saturate at maxweight = 100 (kfusion/mapping_impl.hpp:58-61): 120 frames of the slow room stream -- every block in view
+    from frame 0 has all 512 weights at 100 from frame 99 on -- against the oracle: maps after frames 99, 100, 101 and 119 and the raycast
+    of the last frame, bit for bit; the run must actually contain saturated blocks."""
     W, H, N, dim, mu, frames = 160, 120, 256, 4.8, 0.1, 120
     seen = {"sat_blocks": 0}
 

@@ -73,65 +73,84 @@ def test_stress_stream_parity(name, field, W, H, N, mu, frames, max_blocks):
     gpu.close()
 
 
-@pytest.mark.parametrize("field,mu,frames,max_blocks", [(SDF, 0.1, 48, 0), (OFUSION, 0.02, 40, 0), (SDF, 0.1, 48, 1 << 15), (OFUSION, 0.02, 40, 1 << 15)],
-                         ids=["sdf", "ofusion", "sdf-pooled", "ofusion-pooled"])
-def test_stress_stream_pipelined(field, mu, frames, max_blocks):
-    """The same stream enqueued back to back without synchronisation (scan of frame f+1 beside the raycast of frame f,
-    alternating key lists, occupancy bits published by the sweep): final map bit-exact, and the raycast of EVERY frame
-    bit-exact -- each frame's vertex / normal images are copied into a device ring on the main stream (no host sync), so
-    the raycasts that ran with the next frame's scan beside them are the ones compared (with pooled bricks
-    that scan is writing the index those raycasts read; the last frame alone has no scan beside it).  Pooled maps: the
-    serial schedule (SE_HIP_POOLED_OVERLAP=0) must give the same images."""
+PIPELINED = [
+    # id, field, N, mu, frames, max_blocks
+    ("sdf-512", SDF, 512, 0.1, 48, 0),                 # every occupancy level staged in LDS: the SHALLOW / O32 instantiations
+    ("ofusion-512", OFUSION, 512, 0.02, 40, 0),
+    ("sdf-512-pooled", SDF, 512, 0.1, 48, 1 << 15),
+    ("ofusion-512-pooled", OFUSION, 512, 0.02, 40, 1 << 15),
+    ("sdf-1024", SDF, 1024, 0.1, 30, 0),               # levels beyond the staged ones: the generic (has_deep) instantiations
+    ("sdf-1024-pooled", SDF, 1024, 0.1, 30, 1 << 17),
+    ("ofusion-1024", OFUSION, 1024, 0.02, 24, 0),
+]
+
+
+@pytest.mark.parametrize("streaming", [True, False], ids=["one-queue", "two-queue"])
+@pytest.mark.parametrize("name,field,N,mu,frames,max_blocks", PIPELINED, ids=[c[0] for c in PIPELINED])
+def test_stress_stream_pipelined(name, field, N, mu, frames, max_blocks, streaming):
+    """The stress stream enqueued back to back with NO call between the se_hip_frame calls, every frame's vertex / normal images kept in an
+    image ring (se_hip_set_image_ring) and EVERY slot compared with the oracle's raycast of that frame, bit for bit, plus the final map.
+      one-queue (se_hip_set_streaming): the raycast of frame f runs inside k_raycast_scan, the launch that also scans frame f+1 -- the kernel
+        the benchmark's headline times.  Its scan half inserts into the index (and, pooled bricks, hands out bricks) that its raycast half is
+        reading; asserted through the launch counters: all raycasts but the last (flushed by the final sync) were fused launches.
+      two-queue (the eager schedule): k_raycast on the main stream beside k_alloc_scan on the scan stream, released by the host gate.
+    Pooled maps: the serial schedule (SE_HIP_POOLED_OVERLAP=0) must give the same images."""
     import os
     import torch
     from oracle.binding import OraclePipeline
     from supereight_amd.pipeline import DenseSLAMPipeline
     from supereight_amd.synthetic import StressStream, to_colmajor
-    W, H, N, dim = 320, 240, 512, 4.8
+    W, H, dim = 320, 240, 4.8
     s = StressStream(W, H, dim)
     depths = [s.depth(f) for f in range(frames)]
     poses = [s.pose(f) for f in range(frames)]
     dev = torch.from_numpy(np.stack(depths)).cuda()
     k = np.ascontiguousarray(s.k, np.float32)
+    pcm = [to_colmajor(q) for q in poses]
 
-    def run(expect_overlap=True):
-        # pooled bricks (r03): their raycast reads the index that the next frame's scan, running beside it, is writing (se_block_entry)
+    def run(expect_overlap=True, stream_mode=streaming):
         gpu = DenseSLAMPipeline((W, H), N, dim, field_type=field, max_blocks=max_blocks)
         assert gpu.scan_overlaps() == expect_overlap
         ring = torch.zeros((frames, 2, H, W, 3), dtype=torch.float32, device="cuda")
         assert gpu.image_tile_bytes(H) == ring[0].numel() * 4
+        gpu.set_image_ring(ring.data_ptr(), frames, keepalive=ring)
+        if stream_mode:
+            assert gpu.set_streaming(True) == expect_overlap and gpu.frame_is_fused() == expect_overlap
+        gpu.launch_counts(reset=True)
         for f in range(frames):
-            gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)
-            # r04: se_hip_frame defers the raycast to the next frame call, which launches it in one kernel with that frame's scan
-            # (k_raycast_scan); any other call -- this copy -- launches it first.  Every third frame is copied, so the stream mixes
-            # fused launches (two of three frames) with stand-alone raycasts beside a side-stream scan
-            if f > 2 and (f % 3 == 0 or f == frames - 1):
-                gpu.pack_image_tile(ring[f].data_ptr(), H)     # device-to-device on the pipeline's main stream, behind this frame's raycast
+            assert gpu.frame(dev[f].data_ptr(), pcm[f], k, mu, f) == (3 if f > 2 else 1)      # nothing else is called between the frames
+        n = gpu.launch_counts()
+        if stream_mode and expect_overlap:
+            assert n["pending"] and n["raycast"] == frames - 4 and n["fused"] == frames - 4, n     # frames 3 .. frames-2: fused; the last one is held back
+        else:
+            assert not n["pending"] and n["raycast"] == frames - 3 and n["fused"] == 0, n
+        assert n["integrate"] == frames and n["alloc_scan"] == frames, n
         gpu.sync()
+        n = gpu.launch_counts()
+        assert not n["pending"] and n["raycast"] == frames - 3, n
         return gpu, ring.cpu().numpy()
 
     gpu, ring = run()
     cpu = OraclePipeline(field, N, dim, W, H)
-    worst = {"hitmask_mismatch": 0, "vertex_bit_mismatch_px": 0, "normal_bit_mismatch_px": 0}
     hits = 0
     for f in range(frames):
         cpu.integrate(depths[f], poses[f], s.k, mu, f)
         ran, v_c, n_c = cpu.raycast(poses[f], s.k, mu, f)
-        if ran and (f % 3 == 0 or f == frames - 1):
+        if ran:
             r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": ring[f, 0], "n_g": ring[f, 1]}, dim / N)
             hits += r["hits_gpu"]
-            for kk in worst:
-                worst[kk] = max(worst[kk], r[kk])
             assert r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, (f, r)
+        else:
+            assert not ring[f].any()
     assert hits > 300 * (frames - 3), hits
     m = compare_maps(cpu, gpu)
     assert m["same_block_set"] and m["same_node_set"], m
     assert m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0, m
     assert m["node_x_mismatch"] == 0 and m["node_y_mismatch"] == 0, m
-    v_g, n_g = gpu.vertex_normal()
+    v_g, n_g = gpu.vertex_normal()       # vertex_ / normal_ ARE the last slot
     assert (v_g.view(np.uint32) == ring[frames - 1, 0].view(np.uint32)).all() and (n_g.view(np.uint32) == ring[frames - 1, 1].view(np.uint32)).all()
     cpu.close(); gpu.close()
-    if max_blocks:
+    if max_blocks and streaming:
         os.environ["SE_HIP_POOLED_OVERLAP"] = "0"
         try:
             gpu2, ring2 = run(expect_overlap=False)
@@ -139,3 +158,49 @@ def test_stress_stream_pipelined(field, mu, frames, max_blocks):
             del os.environ["SE_HIP_POOLED_OVERLAP"]
         assert (ring2.view(np.uint32) == ring.view(np.uint32)).all()
         gpu2.close()
+
+
+def test_raw_image_pointers_end_deferral():
+    """se_hip_vertex_normal_device on a streaming handle without an image ring switches deferral off for good: a consumer that reads vertex_ /
+    normal_ through the raw pointers from work of its own, ordered on the handle's stream behind se_hip_frame(f), must find frame f's images --
+    not those of frame f-1, which is what a held-back raycast would leave there.  The handle runs on a torch stream; after each
+    frame the images are copied out on that stream through the raw pointers, without any se_hip call; every copy must be the oracle's."""
+    import torch
+    from oracle.binding import OraclePipeline
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    from supereight_amd.synthetic import SyntheticStream, to_colmajor
+    W, H, N, dim, mu, frames = 160, 120, 256, 2.4, 0.1, 9
+    s = SyntheticStream(W, H, dim)
+    depths = [s.depth(f) for f in range(frames)]
+    poses = [s.pose(f) for f in range(frames)]
+    dev = torch.from_numpy(np.stack(depths)).cuda()
+    k = np.ascontiguousarray(s.k, np.float32)
+    ts = torch.cuda.Stream()
+    gpu = DenseSLAMPipeline((W, H), N, dim, field_type=SDF, streaming=True)
+    gpu.set_stream(ts.cuda_stream)
+    assert gpu.frame_is_fused()
+    for f in range(4):
+        gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)
+    assert gpu.launch_counts()["pending"]                 # frame 3's raycast is held back ...
+    pv, pn = gpu.vertex_normal_device()                   # ... launched by this call, which also ends deferral
+    assert not gpu.frame_is_fused() and not gpu.launch_counts()["pending"]
+
+    class Raw:   # the raw device pointer as a CUDA array for torch
+        def __init__(self, ptr): self.__cuda_array_interface__ = {"shape": (H, W, 3), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    tv, tn = torch.as_tensor(Raw(pv), device="cuda"), torch.as_tensor(Raw(pn), device="cuda")
+    assert tv.data_ptr() == pv and tn.data_ptr() == pn
+    copies = {}
+    for f in range(4, frames):
+        gpu.frame(dev[f].data_ptr(), to_colmajor(poses[f]), k, mu, f)
+        with torch.cuda.stream(ts):                        # the caller's own work on the handle's stream, behind se_hip_frame(f)
+            copies[f] = (tv.clone(), tn.clone())
+    ts.synchronize()
+    assert gpu.launch_counts()["fused"] == 0
+    cpu = OraclePipeline(SDF, N, dim, W, H)
+    for f in range(frames):
+        cpu.integrate(depths[f], poses[f], s.k, mu, f)
+        _, v_c, n_c = cpu.raycast(poses[f], s.k, mu, f)
+        if f in copies:
+            r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": copies[f][0].cpu().numpy(), "n_g": copies[f][1].cpu().numpy()}, dim / N)
+            assert r["hits_gpu"] > 1000 and r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, (f, r)
+    cpu.close(); gpu.close()

@@ -54,6 +54,7 @@ def child(cfg, n):
     gc.collect(); gc.freeze()   # (profiles/r04f_stall_attribution.md)
     warm = 10
     # clock ramp: keep the GPU busy ~150 ms on a throw-away map
+    kw["streaming"] = True    # the one-queue schedule, as bench.py's headline (a per-frame sync flushes: the closed leg is the eager order)
     p = DenseSLAMPipeline((W, H), N, 4.8, field_type=fld, **kw)
     t0 = time.perf_counter()
     f = 0
