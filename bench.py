@@ -295,6 +295,34 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
     return out
 
 
+def cpp_mirror_leg(args, stream, warm: int, n: int):
+    """The drop-in surface itself: examples/denseslam_bench.cpp runs the loop of se_apps/src/benchmark.cpp:115-177 through the C++
+    DenseSLAMSystem mirror (include/se/DenseSLAMSystem.h: preprocessing / setPose / integration / raycasting / synchroniseDevices) on the same
+    frames, in its own process (no Python in the loop), and reports frames/s closed-loop (the reference's bracketing), streaming (the one-queue
+    schedule through integration() + raycasting()) and closed-loop with the per-frame uint16 upload over PCIe."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "examples", "denseslam_bench")
+    if not os.path.exists(exe):
+        return {"error": "examples/denseslam_bench not built (__graft_entry__.build())"}
+    F = warm + n
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as fh:
+        path = fh.name
+        np.asarray([args.width, args.height, F], np.int32).tofile(fh)
+        np.asarray(stream.k, np.float32).reshape(4).tofile(fh)
+        for f in range(F):
+            np.ascontiguousarray(stream.pose(f), np.float32).reshape(16).tofile(fh)
+            np.ascontiguousarray(stream.depth(f), np.float32).reshape(-1).tofile(fh)
+    try:
+        r = subprocess.run([exe, path, str(args.res), str(args.dim), str(args.mu), str(warm), str(n)], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": f"rc={r.returncode} {r.stderr[-400:]}"}
+    return json.loads(line[-1])
+
+
 def stress_leg(args, field, device, n: int):
     """N = 1 leg on the ICL-like stress stream: frames/s pipelined and closed-loop over `n` frames after 10
     warm-up frames, and what the stream does to the map per frame: new keys, swept blocks, blocks that left the frustum
@@ -690,6 +718,12 @@ def main():
         result["ms_per_step_closed_loop"] = 1e3 * (tc1 - tc0) / K
         result["value_note"] = ("value = K pipelined frames / wall time (poses known in advance: scan(f+1) runs beside raycast(f)); "
                                 "value_closed_loop = the same K frames with a device sync after every frame, SURVEY 8(d)'s bracketing")
+    if rank == 0 and world == 1 and not args.no_modes and field == SDF and not args.raw:
+        cm = cpp_mirror_leg(args, stream, warm, min(K, F - warm))
+        result["cpp_mirror"] = cm
+        if "streaming_fps" in cm:
+            result["value_cpp_mirror"] = cm["streaming_fps"]
+            result["value_cpp_mirror_closed_loop"] = cm["closed_loop_fps"]
     if rank == 0 and world == 1 and not args.no_modes:
         result["modes"] = extra_modes(args, field, depth_ptrs, poses, k, warm, min(args.mode_frames, F - warm), local_rank)
         if args.stream != "stress" and not args.raw:

@@ -8,7 +8,7 @@
 //   occ[]      occupancy bit pyramid: one bit per possible octant of every level, Morton order
 //              (the 8 children of an octant share one byte).  It is what the ray traversal walks;
 //              its top levels (37 KB for 512^3) are staged in LDS by the raycast kernel.
-//   vx[], vy[] SoA voxel planes, 512 consecutive floats per block, voxel index x + 8y + 64z
+//   vx[], vy[] SoA voxel planes, 512 consecutive floats per block and plane (interleaved per brick: [512 x | 512 y]), voxel index x + 8y + 64z
 //              (se_core/include/se/node.hpp:139-144).  SDF: x = tsdf, y = weight.
 //              OFusion: x = log-odds, y = last-update time (the reference stores y as double;
 //              every value it ever holds is a float, so float storage is lossless).
@@ -28,12 +28,11 @@
 #include <stdint.h>
 
 #define SE_PENDING 0xFFFFFFFFu
-// Floats from one brick to the next in a voxel plane.  512: vx[] and vy[] are two separate arrays (r01-r02).  1024: one array of
-// 4 KB bricks [512 x | 512 y] and vy = vx + 512 -- a voxel's two values share a 4 KB page (one address translation per get()
-// instead of two; dense maps scatter bricks over 8 / 64 GiB), see DESIGN.md 3.
-#ifndef SE_BRICK_STRIDE
+// Floats from one brick to the next: one array of 4 KB bricks [512 x | 512 y], vy = vx + 512 -- a voxel's two values share a 4 KB page
+// (one address translation per get() instead of two; dense maps scatter bricks over 8 / 64 GiB), see DESIGN.md 3.  The lean march paths
+// (SeDense, se_pooled_index) spell the layout out as shifts: 4 096 bytes per brick, y plane 2 048 bytes behind x.
 #define SE_BRICK_STRIDE 1024
-#endif
+static_assert(SE_BRICK_STRIDE == 1024, "the march paths of se_kernels.h address bricks as [512 x | 512 y] = 4 KB");
 #define SE_MAX_LEVELS 12
 
 enum { C_BLOCKS = 0, C_NODES = 1, C_OVERFLOW = 2, C_COUNT = 8 };
@@ -46,6 +45,10 @@ struct DevMap {
   uint32_t* occ;                  // occupancy bits in heap order: octant (level l, Morton index c) is bit (1 << 3l) | c
   uint32_t* lbits;                // one bit per cell of the block grid, in block_linear order: 'a block is allocated here' (the raycast's march asks it
                                   // before it touches a brick or the index: 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 -- L2-resident)
+  uint32_t* cbits;                // beam start of the raycast: one bit per cell of the COARSE grid (level clevel, linear x + (y << clevel) + (z << 2 clevel)),
+                                  // set for every cell within one cell (27-neighbourhood) of an allocated block: 4 KB at level 5.  A clear bit = no block anywhere
+                                  // within one coarse cell of any point of this cell.  Only ever set (never cleared: blocks are never freed).
+  int clevel;
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
@@ -55,7 +58,6 @@ struct DevMap {
   float* vy;
   uint32_t* bpos;
   uint8_t* bactive;
-  uint8_t* bsat;                  // SDF: 1 = every voxel of the block has reached maxweight (its y plane no longer changes: the sweep neither reads nor writes it)
   float* nx;
   float* ny;
   uint32_t* npos;

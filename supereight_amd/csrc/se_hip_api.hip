@@ -151,12 +151,11 @@ struct se_hip_pipeline {
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
-  size_t occ_words = 0, lbits_words = 0;
+  size_t occ_words = 0, lbits_words = 0, cbits_words = 0;
+  bool beam = true;            // raycast: beam start (se_beam_start); SE_HIP_BEAM=0 switches it off (A/B knob: results are the same either way)
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
-  bool of_scan_tiled = false; // OFusion allocation scan: SE_HIP_OF_SCAN_TILED=1 selects the tiled two-pass kernel (r04: bit-exact, 29.8 us against 18.8 us
-                              // for the one-thread-per-pixel kernel beside the same raycast, profiles/r04d_of_scan_ab.md -- off)
   float* depth_own = nullptr;       // width*height floats
   const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
   unsigned short* depth_mm = nullptr;
@@ -193,6 +192,7 @@ struct se_hip_pipeline {
   int64_t launches[SE_HIP_K_COUNT] = {0};
   int row_begin = 0, row_end = 0;
   int integ_grid = 0;  // > 0: fixed number of workgroups for the integration sweep (tuning knob)
+  bool ieee_sweep = false;   // SE_HIP_IEEE_SWEEP=1: never select the shared-reciprocal sweep (k_integrate<.., FAST = false, ..>)
   unsigned short* tile_cost = nullptr;   // raycast scheduling hint: per wave tile, cost in the previous launch (see RayArgs)
   int* prio_thr = nullptr;               // its three priority thresholds (device; written by the integration sweep)
   bool prio_hint = true;                 // SE_HIP_PRIO=0 switches the hint off
@@ -331,6 +331,12 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.prio_thr = p->prio_thr;
   a.cost_shift = std::max(0, p->leaf_level - 6);
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
+  // beam start: 64 samples on a tile's centre ray, half a coarse cell apart (or whatever spacing covers near .. far)
+  a.beam = p->beam ? 1 : 0;
+  a.beam_cell = m.dim / (float)(1 << m.clevel);
+  a.beam_inv_cell = (float)(1 << m.clevel) / m.dim;
+  a.beam_dt = std::max(0.5f * a.beam_cell, (a.farp - a.nearp) / 64.f);
+  a.inv_dim = 1.f / m.dim;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
   // one workgroup per tile pair, in whole rounds over the compute units (workgroups of the last round beyond the list idle)
@@ -435,9 +441,9 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.lbits, 0, p->lbits_words * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.cbits, 0, p->cbits_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
-  hipMemsetAsync(m.bsat, 0, p->slots, p->stream);
   hipMemsetAsync(m.npos, 0, p->cap_nodes * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.nlevel, 0, p->cap_nodes, p->stream);
   hipMemsetAsync(m.stats, 0, S_COUNT * sizeof(unsigned long long), p->stream);
@@ -450,12 +456,7 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemcpyAsync(m.ctr, ctr0, sizeof ctr0, hipMemcpyHostToDevice, p->stream);
   std::memset(p->ctr_host, 0, C_COUNT * sizeof(uint32_t));
   p->ctr_host[C_NODES] = 1u;
-#if SE_BRICK_STRIDE == 1024
   hipLaunchKernelGGL(k_fill_bricks, dim3(16384), dim3(256), 0, p->stream, m.vx, m.init_x, m.init_y, p->slots * 1024);
-#else
-  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vx, m.init_x, p->slots * 512);
-  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, p->stream, m.vy, m.init_y, p->slots * 512);
-#endif
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.nx, m.init_x, p->cap_nodes * 8);
   hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, p->stream, m.ny, m.init_y, p->cap_nodes * 8);
 }
@@ -492,9 +493,10 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->row_end = (cfg->row_end > cfg->row_begin) ? cfg->row_end : cfg->height;
   if (p->row_begin < 0 || p->row_end > cfg->height) { delete p; return fail(SE_HIP_E_INVALID, "bad row range"); }
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
-  if (const char* ev = std::getenv("SE_HIP_OF_SCAN_TILED")) p->of_scan_tiled = std::atoi(ev) != 0;   // A/B knob
   if (const char* ev = std::getenv("SE_HIP_ICP_LOOKAHEAD")) p->icp_lookahead = std::max(0, std::atoi(ev));   // A/B knob (0: every ICP iteration enqueued up front)
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
+  if (const char* ev = std::getenv("SE_HIP_BEAM")) p->beam = std::atoi(ev) != 0;                   // A/B + test knob
+  if (const char* ev = std::getenv("SE_HIP_IEEE_SWEEP")) p->ieee_sweep = std::atoi(ev) != 0;       // A/B + test knob: the sweep instantiation with the compiler's divisions
 #ifdef SE_DIAG
   if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
 #endif
@@ -569,16 +571,13 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(m.occ, p->occ_words * sizeof(uint32_t));
   p->lbits_words = (cells + 31) / 32;
   ALLOC(m.lbits, p->lbits_words * sizeof(uint32_t));
-#if SE_BRICK_STRIDE == 1024
+  m.clevel = std::min(p->leaf_level, 5);      // coarse cells of dim / 32 (15 cm at 4.8 m): see se_beam_start
+  p->cbits_words = std::max<size_t>(1, ((size_t)1 << (3 * m.clevel)) / 32);
+  ALLOC(m.cbits, p->cbits_words * sizeof(uint32_t));
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
   m.vy = m.vx + 512;
-#else
-  ALLOC(m.vx, slots * 512 * sizeof(float));
-  ALLOC(m.vy, slots * 512 * sizeof(float));
-#endif
   ALLOC(m.bpos, cap * sizeof(uint32_t));
   ALLOC(m.bactive, (slots + 3) & ~(size_t)3);   // whole 32-bit words: se_set_active_once
-  ALLOC(m.bsat, (slots + 3) & ~(size_t)3);
   ALLOC(m.nx, capn * 8 * sizeof(float));
   ALLOC(m.ny, capn * 8 * sizeof(float));
   ALLOC(m.npos, capn * sizeof(uint32_t));
@@ -644,7 +643,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.lbits, m.tab, m.vx, SE_BRICK_STRIDE == 1024 ? nullptr : m.vy, m.bpos, m.bactive, m.bsat, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
+  void* ptrs[] = {m.occ, m.lbits, m.cbits, m.tab, m.vx, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
@@ -913,26 +912,8 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
         else hipLaunchKernelGGL((k_alloc_scan_sdf<false, false>), sgrid, block, 0, s, ms, p->depth, a);
       }
     } else {
-      const int dep[3] = {a.depth_fine, a.depth_mid, a.depth_coarse};
-      bool tiled = p->of_scan_tiled;
-      for (int i = 0; i < 3; ++i) if (a.of_lvl[i] < 1) tiled = false;
-      // the tiled kernel takes "the octant is a block" as "stage 0": true for every volume the reference's step sizes produce
-      // (depths max, max - 4, max - 5 against leaves at max - 3); anything else goes through the one-thread-per-pixel kernel
-      tiled = tiled && dep[0] >= m.leaf_level && dep[1] < m.leaf_level && dep[2] < m.leaf_level && m.off[m.leaf_level] + ((size_t)1 << (3 * m.leaf_level)) < ((size_t)1 << 30);
-      if (tiled) {
-        const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);   // a wave = an 8x8 pixel tile
-        const dim3 sgrid((tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
-        if (m.dense) {
-          if (p->stats) hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<true, true>), sgrid, block, 0, s, ms, p->depth, a);
-          else hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<false, true>), sgrid, block, 0, s, ms, p->depth, a);
-        } else {
-          if (p->stats) hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<true, false>), sgrid, block, 0, s, ms, p->depth, a);
-          else hipLaunchKernelGGL((k_alloc_scan_ofusion_tiled<false, false>), sgrid, block, 0, s, ms, p->depth, a);
-        }
-      } else {
-        if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
-        else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
-      }
+      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
+      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
     }
   }
   if (ov) {
@@ -1090,28 +1071,21 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   mul3(a.R, vs3, a.delta);                           // projective_functor.hpp:76-77
   mul3(a.K3, a.delta, a.cdelta);
   a.mu = mu;
-#ifdef SE_FAST_DIV_MU
-  if (sdf) {
-    // one binade of numerators, exhaustively, for this divisor (the three operations are homogeneous under scaling by powers
-    // of two): ~0.1-0.4 s the first time a mu is seen
-    static float checked_mu = 0.f, checked_inv = 0.f;
-    if (mu != checked_mu) {
-      checked_mu = mu; checked_inv = 0.f;
-      if (mu > 0x1p-60f && mu < 0x1p60f) {
-        const float r = (float)(1.0 / (double)mu);
-        bool ok = true;
-        for (uint32_t m23 = 0; m23 < (1u << 23) && ok; ++m23) {
-          const uint32_t u = 0x3F800000u | m23;
-          float x; std::memcpy(&x, &u, 4);
-          const float q0 = x * r, rem = std::fmaf(-q0, mu, x), q = std::fmaf(rem, r, q0), ref = x / mu;
-          ok = std::memcmp(&q, &ref, 4) == 0;
-        }
-        if (ok) checked_inv = r;
-      }
+  {
+    // The sweep's shared-reciprocal divisions (se_rcp_refined, se_kernels.h) are the IEEE divisions while their operands stay in range; the
+    // host bounds them here for every voxel of the volume: pos = R p + t with 0 <= p < dim on every axis.
+    auto fin = [](float v) { return std::isfinite(v); };
+    bool ok = fin(mu) && mu >= 0x1p-30f && mu <= 0x1p30f && fin(a.voxel) && a.voxel >= 0x1p-60f && m.dim <= 0x1p30f;
+    for (int i = 0; i < 3 && ok; ++i) {
+      float bound = std::fabs(a.t[i]);
+      for (int j = 0; j < 3; ++j) bound += std::fabs(a.R[i * 3 + j]) * m.dim;
+      ok = fin(bound) && bound < 0x1p40f;
     }
-    a.inv_mu = checked_inv;
+    // K of the form getCameraMatrix builds (commons.h:255-262), finite, so that K3 * start needs no products by zero and cam.z == pos.z
+    ok = ok && a.K3[1] == 0.f && a.K3[3] == 0.f && a.K3[6] == 0.f && a.K3[7] == 0.f && a.K3[8] == 1.f;
+    for (int i = 0; i < 9; ++i) ok = ok && fin(a.K3[i]) && std::fabs(a.K3[i]) < 0x1p40f;
+    a.fast_div = (ok && !p->ieee_sweep) ? 1 : 0;
   }
-#endif
   a.maxweight = 100.f;                               // DenseSLAMSystem.cpp:235
   a.timestamp = (1.f / 30.f) * frame;                // DenseSLAMSystem.cpp:243
   a.W = p->cfg.width; a.H = p->cfg.height;
@@ -1148,8 +1122,9 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
     const size_t est = (size_t)p->ctr_host[C_BLOCKS] + (size_t)p->ctr_host[C_BLOCKS] / 8 + 2048;
     const size_t wgs = std::min<size_t>(std::max<size_t>((est + 3) / 4, 2048), 65536);
     const dim3 grid(p->integ_grid > 0 ? (unsigned)p->integ_grid : (unsigned)wgs);
-#define SE_SWEEP(OF, ST, SHD) hipLaunchKernelGGL((k_integrate<OF, ST, SHD>), grid, block, 0, p->stream, m, p->depth, a)
-    switch ((sdf ? 0 : 4) | (p->stats ? 2 : 0) | (a.shard_world > 1 ? 1 : 0)) {
+#define SE_SWEEP(OF, FD, SHD) hipLaunchKernelGGL((k_integrate<OF, FD, SHD>), grid, block, 0, p->stream, m, p->depth, a)
+    a.stats = p->stats ? 1 : 0;
+    switch ((sdf ? 0 : 4) | (a.fast_div ? 2 : 0) | (a.shard_world > 1 ? 1 : 0)) {
       case 0: SE_SWEEP(false, false, false); break;
       case 1: SE_SWEEP(false, false, true); break;
       case 2: SE_SWEEP(false, true, false); break;

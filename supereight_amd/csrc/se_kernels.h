@@ -21,28 +21,12 @@
 #define SE_TILE_W 8     // raycast: a wave covers a SE_TILE_W x SE_TILE_H pixel tile (product 64)
 #define SE_TILE_H 8
 #endif
-#ifndef SE_SPEC
-#define SE_SPEC 2     // SDF march: samples fetched per memory round trip (measured 1 / 2 / 3 / 4: 51.3 / 50.3 / 50.0 / 51.6 us at 512^3, 81 / 77 / 78 / 82 us at 1024^3)
-#endif
-#ifndef SE_SPEC_DEEP
-#define SE_SPEC_DEEP 0  // SDF march through unobserved space (last sample had weight 0): samples per round trip; <= SE_SPEC: off.
-                        // Built and measured in r03 (profiles/r03_ab1_interleave_deepspec.log): 8 samples cut the longest march from 34 to 17
-                        // round trips (tools/march_policy.py) and made the launch SLOWER, 40.5 -> 50.7 us at 512^3, 77 -> 83 us at 1024^3,
-                        // 248 -> 257 us at 2048^3 (4 samples: equal): the extra samples are ~30 VALU instructions and two cold lines each, for
-                        // every lane of a wave in which any lane is in that state, and half of them are fetched past the end of the walk.
-#endif
 #ifndef SE_FUSED_RAY_PRIO
 #define SE_FUSED_RAY_PRIO 1   // k_raycast_scan at <= 512^3: raycast waves start at issue priority 1 instead of 0 (A/B: profiles/r04x_fused_ray_prio_ab.log)
 #endif
 #define SE_SPEC_OF 8  // OFusion march: samples fetched per memory round trip
-#ifndef SE_OF_PREFETCH
-#define SE_OF_PREFETCH 0   // OFusion march on the dense grid: interpolation corners of this many samples per round trip (0: each interpolation fetches its own; se_cast_ray_of_lean)
-#endif
 #ifndef SE_COST_BATCH
 #define SE_COST_BATCH 5   // raycast scheduling: cost of a tile = trips of its slowest ray + SE_COST_BATCH * its march batches (fitted against per-wave clocks in r02)
-#endif
-#ifndef SE_FIRST_LEAF_LITE
-#define SE_FIRST_LEAF_LITE 1   // raycast: stack-free first-leaf search (se_first_leaf_lite); 0 = the iterator with its LDS stack for every ray
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -67,6 +51,25 @@ __device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, 
 
 // Inserts the octant (x,y,z)@level (block if level == leaf_level, else an internal node with no
 // children yet) if absent.  Returns true if this thread created it.
+// A new block marks its coarse cell and the 26 around it in cbits (se_device.h): per (y, z) neighbour the three x-neighbours are adjacent bits of
+// one word (a row of 2^clevel <= 32 cells never straddles a word).  Read first: almost every bit is set already.
+__device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, int bz) {
+  const int C = m.clevel, sh = m.leaf_level - C, n = 1 << C;
+  const int cx = bx >> sh, cy = by >> sh, cz = bz >> sh;
+  const uint32_t row = (cx == 0 ? 3u : (7u << (cx - 1))) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
+#pragma unroll
+  for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int uy = cy + dy, uz = cz + dz;
+      if ((unsigned)uy >= (unsigned)n || (unsigned)uz >= (unsigned)n) continue;
+      const uint32_t base = ((uint32_t)uz << (2 * C)) | ((uint32_t)uy << C);
+      const uint32_t bits = row << (base & 31u);
+      uint32_t* w = m.cbits + (base >> 5);
+      if ((*(volatile uint32_t*)w & bits) != bits) atomicOr(w, bits);
+    }
+}
+
 __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int x, int y, int z) {
   uint32_t* e = m.tab + tab_index(m, level, x, y, z);
   const uint32_t old = atomicCAS(e, 0u, SE_PENDING);
@@ -80,6 +83,7 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
     m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
     occ_set(m, level, x, y, z);
     { const uint32_t lin = block_linear(m, x, y, z); atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u)); }   // (never deferred: a reader that sees the bit early finds PENDING or a brick of initValue())
+    se_mark_coarse(m, x, y, z);   // (never deferred either: an extra bit only makes a raycast's beam start more cautious)
     atomicExch(e, slot + 1u);
   } else {
     const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
@@ -193,9 +197,6 @@ __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& 
 // waves): 34.0 / 38.3 us, 54.8 / 59.0 us, 282 / 289 us.  What stays is the straight-line loop body below.
 // (int)floorf(x), saturating, in one instruction
 __device__ __forceinline__ int se_cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-#ifndef SE_SCAN_INT
-#define SE_SCAN_INT 1   // 1: block coordinates through v_cvt_flr_i32_f32 and one range test on the OR of the three integers (see below)
-#endif
 // (the body of the kernel, so that k_raycast_scan can run it as part of a raycast launch: `bid` = workgroup index within the scan's grid,
 // s_blk_all = SE_SCAN_SLOTS * SE_WG_SCAN words of LDS)
 template <bool STATS, bool DENSE>
@@ -222,10 +223,8 @@ __device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __r
       const f3 origin = f3_sub(worldVertex, f3_scale(a.band * 0.5f, direction));
       const f3 step = f3_div(f3_scale_r(direction, a.band), (float)a.num_steps);
       f3 voxelPos = origin;
-      const float fsize = (float)m.size;
       uint32_t last = 0xFFFFFFFFu;   // last block recorded (probing it again changes nothing)
       int nb = 0;
-#if SE_SCAN_INT
       // floor(s) as an integer in one instruction (v_cvt_flr_i32_f32 saturates, so a coordinate beyond +-2^31 stays outside);
       // 0 <= floor(s.a) < size on all three axes <=> the OR of the three integers has no bit at or above log2(size) (size is a
       // power of two; a negative integer has its sign bit set).  The reference's float tests are false for NaN, the conversion
@@ -250,24 +249,6 @@ __device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __r
         }
         voxelPos = f3_add(voxelPos, step);
       }
-#else
-      for (int i = 0; i < a.num_steps; ++i) {
-        const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
-        const float vx = floorf(s.x), vy = floorf(s.y), vz = floorf(s.z);
-        if ((vx < fsize) && (vy < fsize) && (vz < fsize) && (vx >= 0) && (vy >= 0) && (vz >= 0)) {
-          ++probes;
-          const uint32_t lin = block_linear(m, (int)vx >> 3, (int)vy >> 3, (int)vz >> 3);
-          if (lin != last) {
-            last = lin;
-            if (nb == SE_SCAN_SLOTS) { se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk); nb = 0; }
-            s_blk[nb * SE_WG_SCAN] = lin;
-            ++nb;
-          }
-        }
-        voxelPos = f3_add(voxelPos, step);
-      }
-#endif
-      (void)fsize;
       if (nb) se_scan_flush<STATS, DENSE>(m, a, s_blk, nb, newk);
     }
   }
@@ -341,120 +322,6 @@ __device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float*
 template <bool STATS>
 __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
   se_scan_ofusion_wg<STATS>(m, depthmap, a, (int)blockIdx.x);
-}
-
-// r04, built on VERDICT r03's request, measured, OFF by default (SE_HIP_OF_SCAN_TILED=1): the same scan with the SDF scan's structure.
-// Result (profiles/r04d_of_scan_ab.md, kernel trace + SQ counters, same bench, same box): 29.8 us / 7.3 M VALU / 481 k load instructions per
-// launch against 18.8 us / 5.0 M / 98 k for the kernel above -- whose 74.5 us in r03's trace were not its own: it ran beside a raycast that
-// held 5 x 88 VGPRs per SIMD and left it one wave slot; beside the r04 raycast (68 VGPRs) it gets four.  A ray has only ~10 distinct octants,
-// most consecutive probes repeat the previous one (no load at all in the kernel above), and the record / flush machinery costs more than the
-// round trips it batches.  A wave scans an 8x8 pixel tile; pass 1
-// walks the ray with the reference's float arithmetic and only records the distinct (stage, octant) pairs in LDS; pass 2 fetches
-// the entries of all of them in one round trip (dense bricks, leaf stage: the `active` byte first, the index only for blocks that
-// are not active yet -- which also drops the ~2 byte stores per ray onto a few thousand addresses).  `travelled`, and with it the
-// step size and tree depth of step i, is the same for every ray (only `dist` differs), so level, shift and pyramid offset of a step
-// are wave-uniform.  floor() is taken as an integer in one instruction and the six range tests as one test on the OR, as in
-// k_alloc_scan_sdf (a ray with a non-finite origin or direction is skipped: none of its steps passes the reference's tests).
-// A record = stage << 30 | index into tab[].
-#ifndef SE_OF_SCAN_SLOTS
-#define SE_OF_SCAN_SLOTS 8
-#endif
-template <bool STATS, bool DENSE>
-__device__ __forceinline__ void se_of_scan_flush(const DevMap& m, const AllocArgs& a, const uint32_t* s_rec, int nb, unsigned long long& newk) {
-  uint32_t rec[SE_OF_SCAN_SLOTS], val[SE_OF_SCAN_SLOTS];
-#pragma unroll
-  for (int k = 0; k < SE_OF_SCAN_SLOTS; ++k) rec[k] = s_rec[k * SE_WG_SCAN];
-#pragma unroll
-  for (int k = 0; k < SE_OF_SCAN_SLOTS; ++k) {
-    const uint32_t r = k < nb ? rec[k] : rec[0];
-    const uint32_t ti = r & 0x3FFFFFFFu;
-    val[k] = (DENSE && (r >> 30) == 0u) ? (uint32_t)m.bactive[ti - a.of_off[0]] : m.tab[ti];
-  }
-#pragma unroll
-  for (int k = 0; k < SE_OF_SCAN_SLOTS; ++k) {
-    if (k >= nb) continue;
-    const uint32_t stage = rec[k] >> 30, ti = rec[k] & 0x3FFFFFFFu;
-    const int lvl = stage == 0u ? a.of_lvl[0] : (stage == 1u ? a.of_lvl[1] : a.of_lvl[2]);
-    const uint32_t off = stage == 0u ? a.of_off[0] : (stage == 1u ? a.of_off[1] : a.of_off[2]);
-    const uint32_t lin = ti - off, mask = (1u << lvl) - 1u;
-    const int ox = (int)(lin & mask), oy = (int)((lin >> lvl) & mask), oz = (int)(lin >> (2 * lvl));
-    const bool leaf = stage == 0u;   // tree_depth >= leaves_depth: the octant is a block (the host selects this kernel only if that is stage 0 alone)
-    uint32_t e;
-    if (DENSE && stage == 0u) {
-      if (leaf && val[k]) continue;                  // exists and is active already
-      e = m.tab[ti];
-    } else {
-      e = val[k];
-    }
-    if (e == 0u) {
-      if (se_insert_octant(m, lvl, ox, oy, oz)) { se_append_key(m, lvl, ox, oy, oz); ++newk; }
-    } else if (leaf && e != SE_PENDING) {
-      se_mark_active(m, e - 1u, a.sharded != 0, ox, oy, oz);
-    }
-  }
-}
-template <bool STATS, bool DENSE>
-__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion_tiled(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
-  __shared__ uint32_t s_rec_all[SE_OF_SCAN_SLOTS * SE_WG_SCAN];
-  uint32_t* s_rec = s_rec_all + threadIdx.x;
-  unsigned long long probes = 0, newk = 0;
-  int x, y;
-  bool in_image;
-  {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
-    const int tiles_x = (a.W + 7) >> 3;
-    x = (tile % tiles_x) * 8 + (lane & 7);
-    y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
-    in_image = x < a.W && y < a.row_end;
-  }
-  if (in_image) {
-    const float depth = depthmap[x + y * a.W];
-    if (!(depth == 0)) {
-      const f3 worldVertex = m34_mul_h(a.kpose, {(x + 0.5f) * depth, (y + 0.5f) * depth, depth});
-      const f3 camera = {a.cam[0], a.cam[1], a.cam[2]};
-      const f3 direction = f3_normalized(f3_sub(camera, worldVertex));
-      const f3 origin = f3_sub(worldVertex, f3_scale(a.band * 0.5f, direction));
-      const float dist = sqrtf(f3_sqnorm(f3_sub(camera, origin)));
-      const bool finite = fabsf(origin.x) < INFINITY && fabsf(origin.y) < INFINITY && fabsf(origin.z) < INFINITY &&
-                          fabsf(direction.x) < INFINITY && fabsf(direction.y) < INFINITY && fabsf(direction.z) < INFINITY;
-      const uint32_t hi_mask = ~(uint32_t)(m.size - 1);
-      const float hf_band = a.band, half = a.band * 0.5f;
-      float stepsize = a.voxel;
-      int stage = 0;                 // (tree_depth starts at max_depth: the leaf stage whenever depth_fine does)
-      int lvl = m.max_level < m.leaf_level ? m.max_level : m.leaf_level;
-      uint32_t off = a.of_off[0];
-      f3 voxelPos = origin;
-      uint32_t last = 0xFFFFFFFFu;
-      int nb = 0;
-      for (float travelled = 0.f; finite && travelled < dist; travelled += stepsize) {
-        const f3 s = f3_scale_r(voxelPos, a.inv_voxel);
-        const int ix = se_cvt_flr(s.x), iy = se_cvt_flr(s.y), iz = se_cvt_flr(s.z);
-        if ((((uint32_t)ix | (uint32_t)iy | (uint32_t)iz) & hi_mask) == 0u) {
-          ++probes;
-          const int sh = m.max_level - lvl;
-          const uint32_t lin = ((((uint32_t)iz >> sh) << lvl | ((uint32_t)iy >> sh)) << lvl) | ((uint32_t)ix >> sh);
-          const uint32_t rec = ((uint32_t)stage << 30) | (off + lin);
-          if (rec != last) {
-            last = rec;
-            if (nb == SE_OF_SCAN_SLOTS) { se_of_scan_flush<STATS, DENSE>(m, a, s_rec, nb, newk); nb = 0; }
-            s_rec[nb * SE_WG_SCAN] = rec;
-            ++nb;
-          }
-        }
-        // compute_stepsize / step_to_depth (alloc_impl.hpp:37-51); depths evaluated on the host with the C library's log2f
-        if (travelled < hf_band) { stepsize = a.voxel; stage = 0; }
-        else if (travelled < hf_band + half) { stepsize = 10.f * a.voxel; stage = 1; }
-        else { stepsize = 30.f * a.voxel; stage = 2; }
-        lvl = stage == 0 ? a.of_lvl[0] : (stage == 1 ? a.of_lvl[1] : a.of_lvl[2]);
-        off = stage == 0 ? a.of_off[0] : (stage == 1 ? a.of_off[1] : a.of_off[2]);
-        voxelPos = f3_add(voxelPos, f3_scale_r(direction, stepsize));
-      }
-      if (nb) se_of_scan_flush<STATS, DENSE>(m, a, s_rec, nb, newk);
-    }
-  }
-  se_stat_add<STATS>(m, S_PROBES, probes);
-  se_stat_add<STATS>(m, S_NEWKEYS, newk);
 }
 
 // Octree::allocate for key lists gathered from other ranks (multi-GPU): one thread per key.
@@ -584,14 +451,13 @@ struct IntegArgs {
   float cdelta[3];         // K3 * delta
   float voxel;
   float mu;                // SDF: mu; OFusion: noiseFactor
-#ifdef SE_FAST_DIV_MU
-  float inv_mu;            // RN(1 / mu) if the 3-instruction quotient has been verified for this mu, else 0 (se_sdf_apply_nb)
-#endif
+  int stats;               // count the swept blocks (se_hip_enable_stats)
   float maxweight;
   float timestamp;         // OFusion
   int W, H;
   const float* bspline;    // OFusion: 1000-entry B-spline CDF table
   const float* logodds;    // OFusion: log2f(s/(1-s)) for every (Q1 index, Q2 index) pair, see se_hip_api.hip
+  int fast_div;            // the operands of the sweep's divisions are in the range in which their shared-reciprocal form is the IEEE division (see se_rcp_refined)
   int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan / commit first
   OccLists occ_lists;      // the key lists whose insertions are published
 #ifdef SE_DIAG
@@ -623,58 +489,83 @@ struct IntegArgs {
 //  * 256-bin histogram -> priority thresholds = smallest cost v with #(cost >= v) <= fraction * n;
 //  * counting sort of the tile pairs (tiles 2p, 2p+1: the two waves of one raycast workgroup) by their mean cost ->
 //    order[] = pairs, costliest first (ties in arrival order: scheduling only, never results).
-// cost[] is padded (16-byte loads); hist = 768 words of LDS.
+// cost[] is padded (16-byte loads); hist = 784 words of LDS.
 __device__ __forceinline__ void se_ray_schedule(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist, const int* permille,
                                                 uint32_t* __restrict__ order) {
+  static_assert(SE_WG == 256, "se_ray_schedule: one histogram bin per thread");
   unsigned* phist = hist + 256;   // pairs per mean cost
   unsigned* base = hist + 512;    // first slot of each cost in order[]
-  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0u;
+  unsigned* wsum = hist + 768;    // [2][4] wave totals of the suffix sums
+  int* tmin = (int*)(hist + 776); // [3] thresholds
+  const unsigned tid = threadIdx.x;
+  // The costs, 8 tiles (one 16-byte load) per chunk, chunk c of thread t = t + 256 c: every thread's loads are issued together and stay in registers
+  // for both passes (r05: the function is the critical path of a 512^3 sweep launch -- it was ~20 us of dependent round trips, see k_integrate).
+  // CH chunks per thread cover 20 480 tiles (1280x960: 19 200); tiles beyond that keep the image-order schedule (order[] = identity there).
+  constexpr int CH = 10;
+  const int nch = (n + 7) >> 3;
+  uint4 q[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int c = (int)tid + 256 * j;
+    q[j] = c < nch ? *(const uint4*)(cost + 8 * c) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  hist[tid] = 0u; phist[tid] = 0u;
+  if (tid < 3u) tmin[tid] = 256;
   __syncthreads();
-  const int per = 8 * ((n + 8 * (int)blockDim.x - 1) / (8 * (int)blockDim.x));   // tiles per thread, a multiple of 8
-  const int first = (int)threadIdx.x * per;
-  for (int v = 0; v < per; v += 8) {
-    if (first + v >= n) break;
-    const uint4 q = *(const uint4*)(cost + first + v);
-    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int c = (int)tid + 256 * j;
+    if (c >= nch) continue;
+    const unsigned w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const unsigned c0 = w[e] & 0xFFFFu, c1 = (first + v + 2 * e + 1 < n) ? (w[e] >> 16) : 0u;
-      if (first + v + 2 * e < n) {
-        atomicAdd(&hist[min(c0, 255u)], 1u);
-        if (first + v + 2 * e + 1 < n) atomicAdd(&hist[min(c1, 255u)], 1u);
-        atomicAdd(&phist[min((c0 + c1) >> 1, 255u)], 1u);
-      }
+      const int t0 = 8 * c + 2 * e;
+      if (t0 >= n) continue;
+      const unsigned c0 = w[e] & 0xFFFFu, c1 = (t0 + 1 < n) ? (w[e] >> 16) : 0u;
+      atomicAdd(&hist[min(c0, 255u)], 1u);
+      if (t0 + 1 < n) atomicAdd(&hist[min(c1, 255u)], 1u);
+      atomicAdd(&phist[min((c0 + c1) >> 1, 255u)], 1u);
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned lim[3] = {(unsigned)((long long)n * permille[0] / 1000), (unsigned)((long long)n * permille[1] / 1000), (unsigned)((long long)n * permille[2] / 1000)};
-    int t[3] = {256, 256, 256};
-    unsigned acc = 0u, pacc = 0u;
-    for (int v = 255; v >= 0; --v) {
-      base[v] = pacc;                    // pairs with a higher mean cost come first
-      pacc += phist[v];
-      acc += hist[v];
-      if (v >= 1) {
+  // Suffix sums over the 256 bins, one bin per thread: acc = #(tiles with cost >= v), base[v] = #(pairs with a higher mean cost than v).
+  // Threshold k = the smallest v >= 1 with acc(v) <= lim[k] (acc falls as v rises), 256 if there is none.
+  const unsigned ln = tid & 63u, wv = tid >> 6;
+  const unsigned ph = phist[tid];
+  unsigned a = hist[tid], b = ph;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (acc <= lim[k]) t[k] = v;
-      }
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned ua = __shfl_down(a, o), ub = __shfl_down(b, o);
+    if (ln + o < 64u) { a += ua; b += ub; }
+  }
+  if (ln == 0u) { wsum[wv] = a; wsum[4 + wv] = b; }
+  __syncthreads();
+  for (unsigned w2 = wv + 1; w2 < 4u; ++w2) { a += wsum[w2]; b += wsum[4 + w2]; }
+  base[tid] = b - ph;
+  if (tid >= 1u) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const unsigned lim = (unsigned)((long long)n * permille[k] / 1000);
+      if (a <= lim) atomicMin(&tmin[k], (int)tid);
     }
-    thr[0] = t[0]; thr[1] = t[1]; thr[2] = t[2];
   }
   __syncthreads();
+  if (tid < 3u) thr[tid] = tmin[tid];
   if (order) {
-    for (int v = 0; v < per; v += 8) {
-      if (first + v >= n) break;
-      const uint4 q = *(const uint4*)(cost + first + v);
-      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    // counting sort of the pairs by mean cost, costliest first (ties in arrival order: scheduling only, never results)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (first + v + 2 * e < n) {
-          const unsigned c0 = w[e] & 0xFFFFu, c1 = (first + v + 2 * e + 1 < n) ? (w[e] >> 16) : 0u;
-          const unsigned c = min((c0 + c1) >> 1, 255u);
-          order[base[c] + atomicSub(&phist[c], 1u) - 1u] = (uint32_t)((first + v) / 2 + e);   // phist[c] counts down: a unique slot of c's range
-        }
+    for (int j = 0; j < CH; ++j) {
+      const int c = (int)tid + 256 * j;
+      if (c >= nch) continue;
+      const unsigned w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t0 = 8 * c + 2 * e;
+        if (t0 >= n) continue;
+        const unsigned c0 = w[e] & 0xFFFFu, c1 = (t0 + 1 < n) ? (w[e] >> 16) : 0u;
+        const unsigned cc = min((c0 + c1) >> 1, 255u);
+        order[base[cc] + atomicSub(&phist[cc], 1u) - 1u] = (uint32_t)(4 * c + e);   // phist[cc] counts down: a unique slot of cc's range
+      }
     }
   }
 }
@@ -699,97 +590,83 @@ __device__ __forceinline__ int se_bspline_index(float t) {
   if (t > 3) return 1001;
   return 1000;
 }
-// ---- r03: two voxel slices per instruction.  The sweep is out of VALU issue slots (0.9 of them at 1024^3 / 2048^3) and a
-// third of its instructions are IEEE divisions.  gfx950 executes v_pk_{mul,add,fma}_f32 on two independent floats at the rate of
-// one, so the 8 z-slices of a lane are processed as 4 pairs: every multiplication / addition of the functor is one packed
-// instruction per pair, and the division is the compiler's own correctly rounded sequence (v_div_scale x2, v_rcp, fma, fma, mul,
-// fma, fma, fma, v_div_fmas, v_div_fixup -- AMDGPU's f32 fdiv lowering with denormals on) written out with its six fma / mul steps
-// packed: 16 instructions for two quotients instead of 22.  Same operations on the same operands in the same order per element:
-// the results are the scalar code's bit for bit (no contraction: the fma calls are the division's own).
-// Measured (profiles/r03_ab9_packed_sweep.log): bit-exact on every stream -- the hand-written division IS the compiler's -- and
-// 7 % fewer instructions, but no faster: sweep 26.6 vs 27.7 us at 512^3, 127.9 vs 123.5 at 1024^3, 862 vs 849 at 2048^3, where the
-// kernel runs within 15 % of its own copy-only speed (5.1 TB/s of scattered 2 KB rows).  Off by default, kept as the experiment.
-#ifndef SE_SWEEP_PACKED
-#define SE_SWEEP_PACKED 0
-#endif
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f v2_splat(float s) { return (v2f){s, s}; }
-__device__ __forceinline__ v2f se_div2(v2f a, v2f b) {
-  bool f0, f1, d0, d1;
-  v2f ds, ns, r;
-  ds.x = __builtin_amdgcn_div_scalef(a.x, b.x, false, &d0);
-  ds.y = __builtin_amdgcn_div_scalef(a.y, b.y, false, &d1);
-  ns.x = __builtin_amdgcn_div_scalef(a.x, b.x, true, &f0);
-  ns.y = __builtin_amdgcn_div_scalef(a.y, b.y, true, &f1);
-  r.x = __builtin_amdgcn_rcpf(ds.x);
-  r.y = __builtin_amdgcn_rcpf(ds.y);
-  const v2f nds = -ds;
-  const v2f e0 = __builtin_elementwise_fma(nds, r, v2_splat(1.f));
-  const v2f r1 = __builtin_elementwise_fma(e0, r, r);
-  const v2f q0 = ns * r1;
-  const v2f e1 = __builtin_elementwise_fma(nds, q0, ns);
-  const v2f q1 = __builtin_elementwise_fma(e1, r1, q0);
-  const v2f e2 = __builtin_elementwise_fma(nds, q1, ns);
-  v2f q;
-  q.x = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.x, r1.x, q1.x, f0), b.x, a.x);
-  q.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.y, r1.y, q1.y, f1), b.y, a.y);
-  return q;
+// ---- r05: the sweep's divisions and its square root without the steps that are the identity on its operands ------------------------
+// A block voxel pays five IEEE divisions and one IEEE square root (update_block's 1 / cam.z, sdf_update's pos.x / pos.z, pos.y / pos.z,
+// diff / mu and the weighted average, kfusion/mapping_impl.hpp:35-65): 71 of the ~95 vector instructions of a slice.  AMDGPU lowers
+// n / d (f32, denormals on) to
+//     ds = v_div_scale(d, d, n);  ns = v_div_scale(n, d, n);  r0 = v_rcp(ds);  e0 = fma(-ds, r0, 1);  r1 = fma(e0, r0, r0);
+//     q0 = ns * r1;  e1 = fma(-ds, q0, ns);  q1 = fma(e1, r1, q0);  e2 = fma(-ds, q1, ns);  q = v_div_fmas(e2, r1, q1);  v_div_fixup(q, d, n)
+// v_div_scale hands its operand back unchanged, v_div_fmas is a plain fma and v_div_fixup returns q unless an operand is zero, infinite, NaN
+// or denormal, the numerator is below 2^-103 (the rescaling keeps the residuals e1, e2 exact: their grain is ulp(q) ulp(d), which must not
+// fall below 2^-149), the quotient's exponent leaves [-126, 96) or 1 / d is denormal.  Outside those cases the
+// division IS the eight operations in the middle, three of which (r0, e0, r1) depend on the divisor alone -- so 1 / z, x / z and y / z share
+// them (cam.z == pos.z: K's last row is (0, 0, 1)), and diff / mu takes them from a per-wave constant: 17 + 5 instructions instead of 44,
+// the SAME operations on the SAME operands, hence the same bits, by construction (no lemma, no table).
+// IntegArgs::fast_div is set by the host only when the operands are in that range for every voxel of the volume (se_hip_integrate_sweep:
+// finite pose, |pos| < 2^40 everywhere, 2^-30 <= mu <= 2^30, K of the form getCameraMatrix builds); otherwise the kernel instantiation
+// with the compiler's divisions runs.  What the range check does not cover is harmless where it happens:
+//   * z: a valid voxel has 1e-4 <= pos.z (update_block's own test) -- normal, and 1 / z too; lanes with smaller, NaN or infinite z yield
+//     "not valid" or a NaN diff either way (no update);
+//   * x / z, y / z with |x| < 2^-100: the quotient is below 2^-86 in both forms, its square underflows to +0 -- the only use of it;
+//     a zero numerator gives +-0, squared +0;
+//   * diff / mu: diff is +0 or at least 2^-38 in magnitude (a difference of two floats, one of them >= 1e-4, times a factor >= 1); the
+//     quotient is only looked at through fminf(1, .), which maps every value >= 1, +inf and NaN (an overflowed q0) to 1, and only when
+//     diff > -mu.
+// The weighted average (y x + sdf) / (y + 1) keeps the compiler's division: its operands are stored voxel values nobody bounds.
+struct SeRcp { float nd, r1; };   // -d, and the once-refined reciprocal of d
+__device__ __forceinline__ SeRcp se_rcp_refined(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.f);
+  return {-d, __builtin_fmaf(e0, r0, r0)};
 }
-// sdf_update for a pair of slices (se_sdf_apply_nb twice): returns the two `upd` flags in bits 0 / 1
-__device__ __forceinline__ unsigned se_sdf_apply_nb2(const IntegArgs& a, bool valid0, bool valid1, v2f depthSample, v2f posx, v2f posy, v2f posz, v2f& vx, v2f& vy) {
-  const v2f qx = se_div2(posx, posz), qy = se_div2(posy, posz);
-  const v2f s = (v2_splat(1.f) + qx * qx) + qy * qy;
-  const v2f root = {sqrtf(s.x), sqrtf(s.y)};
-  const v2f diff = (depthSample - posz) * root;
-  const bool upd0 = valid0 && !(depthSample.x <= 0) && (diff.x > -a.mu);
-  const bool upd1 = valid1 && !(depthSample.y <= 0) && (diff.y > -a.mu);
-  const v2f quot = se_div2(diff, v2_splat(a.mu));
-  const v2f sdf = {fminf(1.f, quot.x), fminf(1.f, quot.y)};
-  const v2f avg = se_div2(vy * vx + sdf, vy + v2_splat(1.f));
-  const v2f yn = vy + v2_splat(1.f);
-  vx.x = upd0 ? clampf(avg.x, -1.f, 1.f) : vx.x;
-  vx.y = upd1 ? clampf(avg.y, -1.f, 1.f) : vx.y;
-  vy.x = upd0 ? fminf(yn.x, a.maxweight) : vy.x;
-  vy.y = upd1 ? fminf(yn.y, a.maxweight) : vy.y;
-  return (upd0 ? 1u : 0u) | (upd1 ? 2u : 0u);
+__device__ __forceinline__ float se_div_refined(float n, const SeRcp r) {
+  const float q0 = n * r.r1;
+  const float e1 = __builtin_fmaf(r.nd, q0, n);
+  const float q1 = __builtin_fmaf(e1, r.r1, q0);
+  const float e2 = __builtin_fmaf(r.nd, q1, n);
+  return __builtin_fmaf(e2, r.r1, q1);
 }
+__device__ __forceinline__ float se_inv_refined(const SeRcp r) {   // 1 / d: q0 = 1 * r1 is r1
+  const float e1 = __builtin_fmaf(r.nd, r.r1, 1.f);
+  const float q1 = __builtin_fmaf(e1, r.r1, r.r1);
+  const float e2 = __builtin_fmaf(r.nd, q1, 1.f);
+  return __builtin_fmaf(e2, r.r1, q1);
+}
+// sqrtf(s) for s >= 1 (the functor's 1 + (x/z)^2 + (y/z)^2), +inf or NaN.  AMDGPU's lowering is: scale by 2^32 if s < 2^-96, r = v_sqrt(s),
+// the two neighbours of r tested by exact residuals fma(-r', r, s), scale back, s itself for 0 / +inf.  Here the scaling never triggers and
+// +inf comes out of v_sqrt unchanged (both residuals are NaN, both tests false): what is left are the same nine operations.
+__device__ __forceinline__ float se_sqrt_ge1(float s) {
+  const float r = __builtin_amdgcn_sqrtf(s);
+  const float dn = __uint_as_float(__float_as_uint(r) - 1u), up = __uint_as_float(__float_as_uint(r) + 1u);
+  const float vp = __builtin_fmaf(-dn, r, s), vs = __builtin_fmaf(-up, r, s);
+  float o = (vp <= 0.f) ? dn : r;
+  o = (vs > 0.f) ? up : o;
+  return o;
+}
+// sqrt(1 + (x/z)^2 + (y/z)^2) of sdf_update / bfusion_update (mapping_impl.hpp), the factor that turns a depth difference into a distance along the ray
+template <bool FAST>
+__device__ __forceinline__ float se_ray_factor(f3 pos, const SeRcp rz) {
+  if (FAST) return se_sqrt_ge1(1 + sqf(se_div_refined(pos.x, rz)) + sqf(se_div_refined(pos.y, rz)));
+  return sqrtf(1 + sqf(pos.x / pos.z) + sqf(pos.y / pos.z));
+}
+
 // Branch-free forms for the block sweep: every expression of the functor is evaluated for every lane
 // (results of lanes that the reference skips are discarded by the final selects), so that the 8
-// z-slices of a lane are 8 independent dependency chains the compiler can interleave -- the sweep is
-// bound by the latency of the IEEE division / square-root sequences, not by their count.
-template <bool FASTMU = false>
-__device__ __forceinline__ bool se_sdf_apply_nb(const IntegArgs& a, bool valid, float depthSample, f3 pos, float& vx, float& vy) {
-  const float diff = (depthSample - pos.z) * sqrtf(1 + sqf(pos.x / pos.z) + sqf(pos.y / pos.z));
+// z-slices of a lane are 8 independent dependency chains the compiler can interleave.  `root` = se_ray_factor of the voxel.
+template <bool FAST>
+__device__ __forceinline__ bool se_sdf_apply_nb(const IntegArgs& a, const SeRcp rmu, bool valid, float depthSample, float posz, float root, float& vx, float& vy) {
+  const float diff = (depthSample - posz) * root;
   const bool upd = valid && !(depthSample <= 0) && (diff > -a.mu);
-#ifdef SE_FAST_DIV_MU
-  // Experiment (off in the product build; tools/lemmas/div_exact.c): diff / mu with the correctly rounded
-  // reciprocal r of the run-time constant divisor -- q0 = diff * r, the exact residual, one correction: 3 instructions
-  // instead of the 11 of the IEEE sequence, and the IEEE quotient for every 2^-100 <= |diff| <= 2^100 (the host has checked
-  // one whole binade of numerators for THIS mu before it hands over inv_mu != 0).  Outside that range the result cannot
-  // differ where it is used: diff is +0 (both give +0), or >= 2^-38 in magnitude (a difference of depths >= 1e-4 m, times a
-  // factor >= 1), and for diff > 2^100 both quotients are >= 1 or NaN, which fminf(1, .) turns into 1; negative diff of
-  // that size fails `diff > -mu`.
-  float quot;
-  if (FASTMU) {
-    const float q0 = diff * a.inv_mu;
-    const float rem = __builtin_fmaf(-q0, a.mu, diff);
-    quot = __builtin_fmaf(rem, a.inv_mu, q0);
-  } else {
-    quot = diff / a.mu;
-  }
-  const float sdf = fminf(1.f, quot);
-#else
-  const float sdf = fminf(1.f, diff / a.mu);
-#endif
+  const float sdf = fminf(1.f, FAST ? se_div_refined(diff, rmu) : diff / a.mu);
   const float nx = clampf((vy * vx + sdf) / (vy + 1.f), -1.f, 1.f);
   const float ny = fminf(vy + 1, a.maxweight);
   vx = upd ? nx : vx;
   vy = upd ? ny : vy;
   return upd;
 }
-__device__ __forceinline__ bool se_bfusion_apply_nb(const IntegArgs& a, bool valid, float depthSample, f3 pos, float& vx, float& vy) {
-  const float diff = (pos.z - depthSample) * sqrtf(1 + sqf(pos.x / pos.z) + sqf(pos.y / pos.z));
-  const float sigma = clampf(a.mu * sqf(pos.z), 2 * a.voxel, 0.05f);
+__device__ __forceinline__ bool se_bfusion_apply_nb(const IntegArgs& a, bool valid, float depthSample, float posz, float root, float& vx, float& vy) {
+  const float diff = (posz - depthSample) * root;
+  const float sigma = clampf(a.mu * sqf(posz), 2 * a.voxel, 0.05f);
   const float tt = diff / sigma;
   const int i1 = se_bspline_index(tt), i2 = se_bspline_index(tt - 3);
   const float q1 = a.bspline[i1 < 1000 ? i1 : 0], q2 = a.bspline[i2 < 1000 ? i2 : 0];
@@ -889,31 +766,24 @@ __device__ __forceinline__ void se_update_node_corner(const DevMap& m, const flo
 // build_active_list's predicate (active || in_frustum) is evaluated per block at the top
 // (wave-uniform), update_block's visibility flag is a wave ballot.  Internal nodes (8 corner values
 // each) are swept by the same grid afterwards, one thread per corner.
-// Measured alternatives on MI355X (640x480 -> 512^3, ~10 k swept blocks, this version 29 us):
-// a 512-thread workgroup per block 41-49 us; software prefetch of the next block 32-44 us;
-// separate passes for projection / depth gathers / update 29 us (95 VGPRs instead of 59); 16-byte loads and stores
-// (lane = 4 consecutive x of the rows (y, z) and (y, z+4): the per-row projection twice per lane instead of 8 times,
-// 7 % fewer VALU instructions, 101 VGPRs instead of 91) 28.2 / 135.8 / 877 us against 27.7 / 130.6 / 852 us at
-// 512^3 / 1024^3 / 2048^3 -- the sweep is bound by neither instruction count nor load width.
+// Per block, over the 8 slices of the lane without branches: project the voxel, decide `valid`, form the pixel index and ISSUE the depth
+// gather; then the voxel's ray factor sqrt(1 + (x/z)^2 + (y/z)^2) -- the bulk of the arithmetic, none of it needs the depth sample or the
+// voxel, so it runs under the latency of the 8 gathers and the 16 voxel loads; last the update proper.
+// Measured alternatives on MI355X (640x480 -> 512^3, ~10 k swept blocks, r01-r04 versions 26-29 us): a 512-thread workgroup per block
+// 41-49 us; software prefetch of the next block 32-44 us; 16-byte loads and stores (4 consecutive x per lane) +2 %; two slices per
+// v_pk_* instruction (r03) +-0; skipping the y plane of weight-saturated blocks (r04) +-0 (logs under profiles/, history in profiles/README.md).
+// FAST: the divisions of stages 1-3 in their shared-reciprocal form (se_rcp_refined above; IntegArgs::fast_div).
 // SHARD: the owner-computes variant (IntegArgs::shard_world > 1) -- a template parameter because its packing code costs the
-// plain sweep 11 VGPRs (91 -> 102: 4 waves per SIMD instead of 5, 128 -> 138 us at 1024^3).
+// plain sweep 11 VGPRs.
 #ifndef SE_SWEEP_WAVES
-#define SE_SWEEP_WAVES 5    // > 0: force the register budget of that many waves per SIMD (the packed form needs 98 VGPRs: 5 -> 96 + 12 B of scratch)
+#define SE_SWEEP_WAVES 5    // > 0: force the register budget of that many waves per SIMD
 #endif
 #if SE_SWEEP_WAVES > 0
 #define SE_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(SE_SWEEP_WAVES, SE_SWEEP_WAVES)))
 #else
 #define SE_SWEEP_OCC
 #endif
-#ifndef SE_SWEEP_SAT
-#define SE_SWEEP_SAT 0   // 1: skip the y plane of weight-saturated SDF blocks (see k_integrate).  Built on VERDICT r03's request, bit-exact
-                         // (tests/test_gpu_parity.py::test_weight_saturated_blocks_stay_bit_exact runs either way), measured, OFF: over 260 frames
-                         // the sweep is 27.6 vs 27.0 us at 512^3 and 138 vs 136 us at 1024^3 with it, and 133 vs 123 us at 1024^3 before anything
-                         // has saturated (profiles/r04j_sweep_saturation_ab.log).  A block saturates only if EVERY voxel of it keeps being
-                         // updated; voxels more than mu behind a surface never are (their weight stays 0), so every block the surface passes
-                         // through -- most of the allocated band -- never qualifies, while the flag's byte is one more dependent load per block.
-#endif
-template <bool OFUSION, bool STATS, bool SHARD>
+template <bool OFUSION, bool FAST, bool SHARD>
 __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, const float* __restrict__ depthmap, IntegArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * SE_WG + threadIdx.x) >> 6;
@@ -928,26 +798,32 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
   if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
   if (a.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_count = 0ull;
   if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x, 64u));   // nothing in this kernel reads occ[]; the raycast that follows does
-  __shared__ unsigned s_hist[768];
-  // workgroup 0 computes the next raycast's schedule (a serial 256-step scan in the middle: ~10 us) and therefore takes no
-  // blocks -- with its share of them on top it was the last workgroup of the launch to finish
+  __shared__ unsigned s_hist[784];
+  // workgroup 0 computes the next raycast's schedule and therefore takes no blocks -- with its share of them on top it was the last workgroup of
+  // the launch to finish.  (r01-r04 it WAS the launch: ~22 us of dependent round trips in se_ray_schedule under a 512^3 sweep whose blocks take 18-21 us)
   const bool scheduler = a.prio_thr != nullptr && gridDim.x > 1;
   const int wskip = scheduler ? SE_WG / 64 : 0;
   if (scheduler && blockIdx.x == 0) se_ray_schedule(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille, a.ray_order);
-  for (uint32_t b = (scheduler && blockIdx.x == 0) ? nblocks : (uint32_t)(wave - wskip); b < nblocks; b += (uint32_t)(nwaves - wskip)) {
-    const uint32_t bp = m.bpos[b];
+  const SeRcp rmu = se_rcp_refined(a.mu);   // (FAST, SDF: the divisor-only part of diff / mu, once per wave)
+  // (the block position of the next iteration is loaded an iteration ahead, and the first one beside the counters rather than behind them: in bounds
+  // whatever the counter says.  Voxel loads in front of the active test -- one dependent round trip less per block -- measured +-0 at 512^3, -3 % at
+  // 1024^3 and +2 % on the stress stream, where half the blocks are inactive and their bricks would be read for nothing: not done.
+  // profiles/r05e_sched_ab.log)
+  const uint32_t stride = (uint32_t)(nwaves - wskip);
+  uint32_t b = (scheduler && blockIdx.x == 0) ? 0xFFFFFFFFu : (uint32_t)(wave - wskip);
+  uint32_t bp_next = m.bpos[min(b, m.cap_blocks - 1u)];
+  for (; b < nblocks; b += stride) {
+    const uint32_t bp = bp_next;
+    bp_next = m.bpos[min(b + stride, m.cap_blocks - 1u)];
     const int bx = (int)(bp & 1023u) << 3, by = (int)((bp >> 10) & 1023u) << 3, bz = (int)(bp >> 20) << 3;
     if (SHARD && (unsigned)((bx >> 3) + (by >> 3) + (bz >> 3)) % (unsigned)a.shard_world != (unsigned)a.shard_rank) continue;
     const uint32_t slot = block_slot(m, b, bp);
-    if (!m.bactive[slot] && !se_in_frustum(a, bx, by, bz)) continue;
-    if (STATS && lane == 0) ++swept;
-    float* px = m.vx + (size_t)slot * SE_BRICK_STRIDE + lane;
-    float* py = m.vy + (size_t)slot * SE_BRICK_STRIDE + lane;
-    // r04, fewer bytes: once all 512 weights of an SDF block have reached maxweight, sdf_update's y <- fminf(y + 1, maxweight)
-    // (kfusion/mapping_impl.hpp:58-61) is the identity on it for good (weights never decrease, bricks are never recycled): the y
-    // plane is neither read nor written any more -- half of the block's traffic.  The flag is set by the sweep that first sees it.
-    const bool sat = !OFUSION && SE_SWEEP_SAT && __builtin_amdgcn_readfirstlane((int)m.bsat[slot]) != 0;   // (one block per wave: a scalar)
+    float* px = m.vx + (size_t)slot * 1024 + lane;
+    float* py = px + 512;
     float vx[8], vy[8];
+    const unsigned char act = m.bactive[slot];
+    if (!act && !se_in_frustum(a, bx, by, bz)) continue;
+    if (a.stats && lane == 0) ++swept;
 #ifdef SE_DIAG
     if (a.debug == 2) {
 #pragma unroll
@@ -956,11 +832,7 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
 #endif
     {
 #pragma unroll
-      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = a.maxweight; }
-      if (!sat) {
-#pragma unroll
-        for (int zi = 0; zi < 8; ++zi) vy[zi] = py[zi * 64];
-      }
+      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
     }
 #ifdef SE_DIAG
     if (a.debug == 1) {
@@ -971,107 +843,56 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
 #endif
     bool visible = false;
     const int y = by + ly;
-    // update_block (projective_functor.hpp:73-111) in stages over the 8 z-slices of the lane, without
-    // branches: each stage is 8 independent copies of the same short dependency chain.
-    bool upd[8];
-#if SE_SWEEP_PACKED
-    if (!OFUSION) {
-      // the part of R * p that does not depend on z, and the per-lane x offsets (the scalar code's own subexpressions)
-      const float px_ = bx * a.voxel, py_ = y * a.voxel;
-      const float hx = a.R[0] * px_ + a.R[1] * py_, hy = a.R[3] * px_ + a.R[4] * py_, hz = a.R[6] * px_ + a.R[7] * py_;
-      const float cdx = fx * a.cdelta[0], cdy = fx * a.cdelta[1], cdz = fx * a.cdelta[2];
-      const float ddx = fx * a.delta[0], ddy = fx * a.delta[1], ddz = fx * a.delta[2];
-      // two halves of two slice pairs each: the projected positions of only four slices are alive across the depth gathers
-      // (all eight: 102 VGPRs = 4 waves per SIMD instead of 5)
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        v2f posx[2], posy[2], posz[2], dsp[2];
-        int pidx[4];
-        bool valid[4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k2 = 2 * half + j;
-          const v2f pz = {(bz + 2 * k2) * a.voxel, (bz + 2 * k2 + 1) * a.voxel};
-          const v2f sx = (v2_splat(hx) + a.R[2] * pz) + v2_splat(a.t[0]);
-          const v2f sy = (v2_splat(hy) + a.R[5] * pz) + v2_splat(a.t[1]);
-          const v2f sz = (v2_splat(hz) + a.R[8] * pz) + v2_splat(a.t[2]);
-          const v2f csx = (a.K3[0] * sx + a.K3[1] * sy) + a.K3[2] * sz;
-          const v2f csy = (a.K3[3] * sx + a.K3[4] * sy) + a.K3[5] * sz;
-          const v2f csz = (a.K3[6] * sx + a.K3[7] * sy) + a.K3[8] * sz;
-          const v2f cvx = csx + v2_splat(cdx), cvy = csy + v2_splat(cdy), cvz = csz + v2_splat(cdz);
-          posx[j] = sx + v2_splat(ddx); posy[j] = sy + v2_splat(ddy); posz[j] = sz + v2_splat(ddz);
-          const v2f inverse_depth = se_div2(v2_splat(1.f), cvz);
-          const v2f pixx = cvx * inverse_depth + v2_splat(0.5f);
-          const v2f pixy = cvy * inverse_depth + v2_splat(0.5f);
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float pzv = e ? posz[j].y : posz[j].x, pxx = e ? pixx.y : pixx.x, pyy = e ? pixy.y : pixy.x;
-            const bool v = !(pzv < 0.0001f) && !(pxx < 0.5f || pxx > a.W - 1.5f || pyy < 0.5f || pyy > a.H - 1.5f);
-            valid[2 * j + e] = v;
-            visible = visible || v;
-            pidx[2 * j + e] = v ? cvt_i32(pxx) + a.W * cvt_i32(pyy) : 0;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dsp[j] = (v2f){depthmap[pidx[2 * j]], depthmap[pidx[2 * j + 1]]};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k2 = 2 * half + j;
-          v2f x2 = {vx[2 * k2], vx[2 * k2 + 1]}, y2 = {vy[2 * k2], vy[2 * k2 + 1]};
-          const unsigned u = se_sdf_apply_nb2(a, valid[2 * j], valid[2 * j + 1], dsp[j], posx[j], posy[j], posz[j], x2, y2);
-          vx[2 * k2] = x2.x; vx[2 * k2 + 1] = x2.y; vy[2 * k2] = y2.x; vy[2 * k2 + 1] = y2.y;
-          upd[2 * k2] = (u & 1u) != 0u; upd[2 * k2 + 1] = (u & 2u) != 0u;
-        }
-      }
-    } else
-#endif
-    {
-    f3 pos[8];
+    // update_block (projective_functor.hpp:73-111)
     int pidx[8];
-    bool valid[8];
-    float ds[8];
+    bool valid[8], upd[8];
+    float ds[8], posz[8], root[8];
+    // stages 1 + 2 per slice: projection, validity, pixel, the depth gather is issued, then the ray factor (which needs neither the depth sample
+    // nor the voxel: it runs under the latency of the gathers and of the 16 voxel loads above)
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
       const int z = bz + zi;
       const f3 start = f3_add(m3_mul(a.R, {bx * a.voxel, y * a.voxel, z * a.voxel}), {a.t[0], a.t[1], a.t[2]});
-      const f3 camerastart = m3_mul(a.K3, start);
-      const f3 camera_voxel = f3_add(camerastart, f3_scale(fx, {a.cdelta[0], a.cdelta[1], a.cdelta[2]}));
-      pos[zi] = f3_add(start, f3_scale(fx, {a.delta[0], a.delta[1], a.delta[2]}));
-      const float inverse_depth = 1.f / camera_voxel.z;
-      const float pixx = camera_voxel.x * inverse_depth + 0.5f;
-      const float pixy = camera_voxel.y * inverse_depth + 0.5f;
-      valid[zi] = !(pos[zi].z < 0.0001f) && !(pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f);
+      const f3 pos = f3_add(start, f3_scale(fx, {a.delta[0], a.delta[1], a.delta[2]}));
+      float cvx, cvy, inverse_depth;
+      SeRcp rz = {0.f, 0.f};
+      if (FAST) {
+        // K3 = [fx 0 cx; 0 fy cy; 0 0 1] (checked by the host): K3 * start without its products by zero -- (a + 0 * s) + b and a + b differ only in
+        // the sign of an exactly-zero sum, which `pix = cam * inverse_depth + 0.5` does not see; row 2 gives cam.z == pos.z
+        cvx = (a.K3[0] * start.x + a.K3[2] * start.z) + fx * a.cdelta[0];
+        cvy = (a.K3[4] * start.y + a.K3[5] * start.z) + fx * a.cdelta[1];
+        rz = se_rcp_refined(pos.z);
+        inverse_depth = se_inv_refined(rz);
+      } else {
+        const f3 camera_voxel = f3_add(m3_mul(a.K3, start), f3_scale(fx, {a.cdelta[0], a.cdelta[1], a.cdelta[2]}));
+        cvx = camera_voxel.x; cvy = camera_voxel.y;
+        inverse_depth = 1.f / camera_voxel.z;
+      }
+      const float pixx = cvx * inverse_depth + 0.5f;
+      const float pixy = cvy * inverse_depth + 0.5f;
+      valid[zi] = !(pos.z < 0.0001f) && !(pixx < 0.5f || pixx > a.W - 1.5f || pixy < 0.5f || pixy > a.H - 1.5f);
       visible = visible || valid[zi];
       // sdf_update / bfusion_update: pixel.cast<int>().  A valid pixel lies in [0.5, W - 1.5] x [0.5, H - 1.5], where the hardware conversion (one
       // instruction) equals the x86 cast; an invalid one reads pixel 0 and is discarded (NaN cannot be valid: it needs camera_voxel.z == 0 == pos.z)
       pidx[zi] = valid[zi] ? se_cvt_hw(pixx) + a.W * se_cvt_hw(pixy) : 0;
+      ds[zi] = depthmap[pidx[zi]];
+      posz[zi] = pos.z;
+      root[zi] = se_ray_factor<FAST>(pos, rz);
     }
+    // stage 3: the functor
 #pragma unroll
-    for (int zi = 0; zi < 8; ++zi) ds[zi] = depthmap[pidx[zi]];
-#ifdef SE_FAST_DIV_MU
-    if (!OFUSION && a.inv_mu != 0.f) {
-#pragma unroll
-      for (int zi = 0; zi < 8; ++zi) upd[zi] = se_sdf_apply_nb<true>(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
-    } else
-#endif
-    {
-#pragma unroll
-      for (int zi = 0; zi < 8; ++zi)
-        upd[zi] = OFUSION ? se_bfusion_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]) : se_sdf_apply_nb(a, valid[zi], ds[zi], pos[zi], vx[zi], vy[zi]);
-    }
-    }
+    for (int zi = 0; zi < 8; ++zi)
+      upd[zi] = OFUSION ? se_bfusion_apply_nb(a, valid[zi], ds[zi], posz[zi], root[zi], vx[zi], vy[zi])
+                        : se_sdf_apply_nb<FAST>(a, rmu, valid[zi], ds[zi], posz[zi], root[zi], vx[zi], vy[zi]);
     // a voxel the functor left alone is written back unchanged only if a neighbour in the same 256-byte
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
-    bool full = true;
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
 #ifdef SE_DIAG
       if (a.debug == 2) { if (vx[zi] == 12345.f) px[zi * 64] = vx[zi]; continue; }   // keep the arithmetic alive
 #endif
-      if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; if (!sat) py[zi * 64] = vy[zi]; }
-      full = full && (vy[zi] == a.maxweight);
+      if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
-    if (!OFUSION && SE_SWEEP_SAT && !sat && __ballot(full) == ~0ull && lane == 0) m.bsat[slot] = 1;
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
     if (SHARD) {   // the other replicas get this block's flag and, if anything of it was in view, its voxels
@@ -1096,7 +917,7 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
       }
     }
   }
-  if (STATS && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
+  if (a.stats && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
   for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG)
     se_update_node_corner<OFUSION>(m, depthmap, a, tid);
 }
@@ -1160,6 +981,9 @@ struct RayArgs {
   uint32_t cache_codes;  // heap codes below this value are staged (= 2 * 8^cache_levels)
   int has_deep;          // there are non-leaf levels beyond the staged ones (volumes > 512^3)
   int stack_depth;   // ray stack slots (= leaf level)
+  // Beam start (r05; results do not depend on it, see se_beam_start): sample spacing along the tile's centre ray, edge of a coarse cell, its inverse, 1 / dim
+  int beam;
+  float beam_dt, beam_cell, beam_inv_cell, inv_dim;
   // Scheduling (results do not depend on it).  tile_cost[] = cost of every wave tile (8x8 pixels) in the previous
   // raycast launch, trips + 5 * march batches of its slowest ray.  All waves of a 640x480 launch are resident from the
   // first microsecond, every SIMD works through the 4-5 tiles the dispatcher gives it, and the launch lasts as long as the
@@ -1630,9 +1454,13 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
 // What a trip then needs from memory is the 8 sibling bits of the current parent (byte `parent` of the heap-ordered
 // occupancy bits): one LDS byte per descent or pop instead of a word per trip; leaf parents take theirs from the 64
 // leaf bits of their own parent, fetched one level earlier as before.
+// t_start (r05, units of dim like every t here; 0 = none): the search enters the tree at max(t_min, t_start) instead of t_min.  The caller guarantees
+// (se_beam_start) that no allocated block lies within centimetres of the ray before t_start, so the first leaf and the plane through which the ray
+// enters it are the same -- and t_min at the leaf is that plane's time, `plane * t_coef - t_bias` of the cell left last, whatever cells came before.
+// Should the search end without ever having advanced (t_min still t_start: it would be returning t_start as an entry time) the ray is handed back.
 template <bool SHALLOW, typename Hook = SeNoHook>
 __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const RayArgs& a, f3 origin, f3 direction, const uint32_t* s_occ,
-                                                      bool& redo, Hook before_loop = Hook(), bool live = true) {
+                                                      bool& redo, Hook before_loop = Hook(), bool live = true, float t_start = 0.f) {
   f3 pos = {1.0f, 1.0f, 1.0f};
   uint32_t parent = 1u;  // root
   float scale_exp2 = 0.5f;
@@ -1655,6 +1483,8 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
   const float t_lim = fminf(h0, a.far_n);   // t_max_init: all the t_max this loop knows
   const float tmax_m = t_lim * m.dim;
   redo = live && !(t_min < h0);             // irregular set-up (a ray that misses the volume, any NaN): full iterator
+  const bool jumped = t_start > t_min;
+  t_min = jumped ? t_start : t_min;
   if (1.5f * t_coef.x - t_bias.x > t_min) pos.x = 1.5f;
   if (1.5f * t_coef.y - t_bias.y > t_min) pos.y = 1.5f;
   if (1.5f * t_coef.z - t_bias.z > t_min) pos.z = 1.5f;
@@ -1719,6 +1549,7 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
     }
   }
 #undef SE_SIB_OF
+  if (jumped && t_min == t_start) redo = true;
   return {t_min * m.dim, tmax_m, guard};
 }
 
@@ -1744,9 +1575,6 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 //    < 1): in free or unobserved space they were ~100 instructions and 8 loads per batch that nobody used.  A sample
 //    that turns out to need them without having them pays one extra round trip (se_interp), results unchanged;
 //  * `(double)f_tt <= 0.1` is `f_tt < 0.1f` (0.1f is the smallest float above 0.1): no double-precision compare.
-#ifndef SE_MARCH_LEAN
-#define SE_MARCH_LEAN 1
-#endif
 #ifndef SE_MARCH_SKIP
 #define SE_MARCH_SKIP 4    // SDF march in unobserved space: positions asked of the leaf bitmap per round trip (se_march_skip); 0 = off.  Measured 0 / 4 / 8
                            // (profiles/r04p_march_skip_ab.log): 59.8 / 59.8 / 61.6 us per frame at 512^3, 193.8 / 188.4 / 189.5 at 1024^3, stress 69.7 / 68.6 / 71.3
@@ -2152,58 +1980,6 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) { qx[i] = A::ldx(m, sm[i].vi); qy[i] = A::ldy(m, sm[i].vi); }
     bool stop = false;
-#if SE_OF_PREFETCH
-    // Inside the band in front of a surface EVERY sample is interpolated (x > -100 && y > 0: observed) until the hit: up to eight dependent round
-    // trips per batch when each interpolation fetches its own corners.  Here the samples of a batch are taken SE_OF_PREFETCH at a time: the corner
-    // values of those that will be interpolated (known from the batch's own x / y, already here) are fetched together, then the samples are consumed
-    // in order from registers -- same values, same operations, same order; corners of samples behind a hit were fetched for nothing.
-    unsigned obs = 0u;      // bit i: sample i exists (t < tfar) and is observed
-#pragma unroll
-    for (int i = 0; i < SE_SPEC_OF; ++i) {
-      const float dx = sm[i].in ? qx[i] : fc.init_x, dy = sm[i].in ? qy[i] : fc.init_y;
-      if (tt[i] < tfar && dx > -100.f && dy > 0.f) obs |= 1u << i;
-    }
-#pragma unroll
-    for (int h = 0; h < SE_SPEC_OF / SE_OF_PREFETCH; ++h) {
-      float pc[SE_OF_PREFETCH][8], cfx[SE_OF_PREFETCH], cfy[SE_OF_PREFETCH], cfz[SE_OF_PREFETCH];
-      bool inside[SE_OF_PREFETCH];
-#pragma unroll
-      for (int j = 0; j < SE_OF_PREFETCH; ++j) {
-        const int i = SE_OF_PREFETCH * h + j;
-        inside[j] = false;
-        if (!stop && ((obs >> i) & 1u)) {
-          const SeCell<O32> cell = se_cell_lean<O32>(m, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, tt[i]))));
-          inside[j] = cell.inside;
-          cfx[j] = cell.fx; cfy[j] = cell.fy; cfz[j] = cell.fz;
-          if (cell.inside) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) pc[j][k] = A::ldx(m, cell.vi[k]);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < SE_OF_PREFETCH; ++j) {
-        const int i = SE_OF_PREFETCH * h + j;
-        if (stop) continue;
-        t = tt[i];
-        if (!(t < tfar)) { done = true; stop = true; continue; }
-        if (STATS) ++rc.n_get;
-        if ((obs >> i) & 1u) {
-          if (inside[j]) {
-            const float fx = cfx[j], fy = cfy[j], fz = cfz[j];
-            const float* pk = pc[j];
-            f_tt = (((pk[0] * (1 - fx) + pk[1] * fx) * (1 - fy) + (pk[2] * (1 - fx) + pk[3] * fx) * fy) * (1 - fz) +
-                    ((pk[4] * (1 - fx) + pk[5] * fx) * (1 - fy) + (pk[6] * (1 - fx) + pk[7] * fx) * fy) * fz);
-          } else {
-            f_tt = se_interp_generic<true>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, tt[i]))), c);   // a corner outside the volume
-          }
-          if (STATS) ++rc.n_interp;
-        }
-        if (f_tt > 0.f) { done = true; stop = true; continue; }
-        f_t = f_tt;
-      }
-    }
-#else
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) {
       if (stop) continue;
@@ -2218,7 +1994,6 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
       if (f_tt > 0.f) { done = true; stop = true; continue; }
       f_t = f_tt;
     }
-#endif
     if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
   }
   if (f_tt > 0.f) {
@@ -2231,187 +2006,43 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
 template <bool OFUSION, bool STATS, bool DENSE, bool O32 = false>
 __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
                                             BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
-  if (SE_MARCH_LEAN && !OFUSION && DENSE) { se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
-  if (SE_MARCH_LEAN && OFUSION && DENSE) { se_cast_ray_of_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
-  if (SE_MARCH_LEAN && !OFUSION && !DENSE) { se_cast_ray_sdf_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
-  if (SE_MARCH_LEAN && OFUSION && !DENSE) { se_cast_ray_of_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc); return; }
-  unsigned long long& n_get = rc.n_get;
-  unsigned long long& n_interp = rc.n_interp;
-  {
-    const float tnear = t_min;
-    if (!OFUSION) {
-      // raycast(const Volume<SDF>&...) (se_denseslam/src/kfusion/rendering_impl.hpp:34-74)
-      if (tnear < tfar) {
-        float t = tnear;
-        float stepsize = a.largestep;
-        f3 position = f3_add(org, f3_scale_r(dir, t));
-        float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
-        if (STATS) ++n_interp;
-        float f_tt = 0;
-        if (f_t > 0) {
-          // The march is a chain of dependent memory round trips (sample -> step size -> next
-          // position).  Most steps repeat the previous step size (largestep through unobserved
-          // space, mu through observed free space where tsdf == 1), so SE_SPEC samples at
-          // position + k * S * dir are fetched in one round trip and consumed in order for as long
-          // as the step actually taken equals the predicted S bit for bit -- the positions are
-          // formed by the same float additions the sequential loop performs.
-          float S = a.largestep;
-          bool done = false;
-          // `deep`: the last sample consumed read weight 0 (unobserved space, almost always an unallocated block), so the march is
-          // walking in largesteps and will keep doing so until it reaches the next surface band -- the longest dependent chains of
-          // a launch are such walks behind silhouettes and depth edges (tools/march_policy.py: 34 round trips for the slowest ray
-          // of a 1024^3 frame, 17 with 8 samples per round trip there).  SE_SPEC_DEEP samples ride on one round trip in that state;
-          // everywhere else a batch stays SE_SPEC samples (every extra sample is ~25 VALU instructions the bulk of the rays would
-          // pay for nothing: uniform batches of 4 measured slower).
-          bool deep = false;
-          for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
-            ++rc.n_batch;
-            constexpr int NS = SE_SPEC_DEEP > SE_SPEC ? SE_SPEC_DEEP : SE_SPEC;
-            f3 q[SE_SPEC];
-            uint32_t qe[SE_SPEC];
-            float qx[NS], qy[NS];
-            int qi[SE_SPEC][3];
-            q[0] = position;
-#pragma unroll
-            for (int i = 1; i < SE_SPEC; ++i) q[i] = f3_add(q[i - 1], f3_scale(S, dir));
-#pragma unroll
-            for (int i = 0; i < SE_SPEC; ++i) {
-              // VolumeTemplate::get -> get_fine (volume_template.hpp:77-83)
-              qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
-              qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < SE_SPEC; ++i) {
-              const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
-              qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
-            }
-            uint32_t qvalid = 0u;   // bit i: sample i lies inside the volume (and, pooled bricks, in an allocated block)
-#pragma unroll
-            for (int i = 0; i < SE_SPEC; ++i) qvalid |= qe[i] ? (1u << i) : 0u;
-            const int depth = (SE_SPEC_DEEP > SE_SPEC && deep) ? SE_SPEC_DEEP : SE_SPEC;
-            if (SE_SPEC_DEEP > SE_SPEC && deep) {
-              // positions by the same float additions the sequential loop performs (position += largestep * dir)
-              f3 qq = q[SE_SPEC - 1];
-#pragma unroll
-              for (int i = SE_SPEC; i < NS; ++i) {
-                qq = f3_add(qq, f3_scale(S, dir));
-                const int ix = cvt_i32(a.inv_voxel * qq.x), iy = cvt_i32(a.inv_voxel * qq.y), iz = cvt_i32(a.inv_voxel * qq.z);
-                const uint32_t e = in_volume(m, ix, iy, iz) ? se_block_entry<DENSE>(m, ix >> 3, iy >> 3, iz >> 3, c) : 0u;
-                const size_t vi = e ? se_voxel_index(e, ix, iy, iz) : 0;
-                qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
-                qvalid |= e ? (1u << i) : 0u;
-              }
-            }
-            // Near the surface every step changes the step size, so a batch ends after its first sample
-            // and that sample usually wants the interpolated value: on the dense grid its 8 corners ride
-            // along with the gets instead of costing a round trip of their own.
-            InterpCell cell0;
-            float cv0[8];
-            if (DENSE) {
-              size_t vi0[8];
-              cell0 = se_interp_cell_dense(m, fc, f3_scale(a.inv_voxel, q[0]), vi0);
-#pragma unroll
-              for (int k = 0; k < 8; ++k) cv0[k] = m.vx[vi0[k]];
-            }
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-              if (i >= depth) break;
-              if (!(t < tfar)) { done = true; break; }
-              if (STATS) ++n_get;
-              const bool ok = (qvalid >> i) & 1u;
-              const float dx = ok ? qx[i] : fc.init_x, dy = ok ? qy[i] : fc.init_y;
-              deep = dy == 0;
-              if (dy == 0) {
-                stepsize = a.largestep;
-                position = f3_add(position, f3_scale(stepsize, dir));
-              } else {
-                f_tt = dx;
-                if ((double)f_tt <= 0.1 && f_tt >= -0.5f) {
-                  if (DENSE && i == 0) {
-                    f_tt = se_interp_blend(cell0, cv0);
-                  } else {
-                    // (pooled bricks: the block of this sample as the look-up hint -- known for the samples of the regular batch)
-                    if (i < SE_SPEC) { c.bx = qi[i < SE_SPEC ? i : 0][0] >> 3; c.by = qi[i < SE_SPEC ? i : 0][1] >> 3; c.bz = qi[i < SE_SPEC ? i : 0][2] >> 3; c.e = qe[i < SE_SPEC ? i : 0]; }
-                    f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, position), c);
-                  }
-                  if (STATS) ++n_interp;
-                }
-                if (f_tt < 0) { done = true; break; }
-                stepsize = fmaxf(f_tt * a.mu, a.step);
-                position = f3_add(position, f3_scale(stepsize, dir));
-                f_t = f_tt;
-              }
-              t += stepsize;
-              if (stepsize != S) { S = stepsize; break; }
-            }
-          }
-          if (f_tt < 0) {
-            t = t + stepsize * f_tt / (f_t - f_tt);
-            const f3 r = f3_add(org, f3_scale_r(dir, t));
-            hx = r.x; hy = r.y; hz = r.z; hw = t;
-          }
-        }
-      }
-    } else {
-      // raycast(const Volume<OFusion>&...) (se_denseslam/src/bfusion/rendering_impl.hpp:35-68)
-      if (tnear < tfar) {
-        float t = tnear;
-        const float stepsize = a.step;
-        float f_t = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, f3_add(org, f3_scale_r(dir, t))), c);
-        if (STATS) ++n_interp;
-        float f_tt = 0;
-        if (f_t <= 0.f) {
-          // fixed step: every sample position origin + dir * t_k with t_k+1 = t_k + step is known in
-          // advance, so SE_SPEC_OF gets share one memory round trip
-          bool done = false;
-          for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
-            ++rc.n_batch;
-            float tt[SE_SPEC_OF];
-            f3 q[SE_SPEC_OF];
-            uint32_t qe[SE_SPEC_OF];
-            float qx[SE_SPEC_OF], qy[SE_SPEC_OF];
-            int qi[SE_SPEC_OF][3];
-            tt[0] = t;
-#pragma unroll
-            for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
-#pragma unroll
-            for (int i = 0; i < SE_SPEC_OF; ++i) {
-              q[i] = f3_add(org, f3_scale_r(dir, tt[i]));
-              qi[i][0] = cvt_i32(a.inv_voxel * q[i].x); qi[i][1] = cvt_i32(a.inv_voxel * q[i].y); qi[i][2] = cvt_i32(a.inv_voxel * q[i].z);
-              qe[i] = in_volume(m, qi[i][0], qi[i][1], qi[i][2]) ? se_block_entry<DENSE>(m, qi[i][0] >> 3, qi[i][1] >> 3, qi[i][2] >> 3, c) : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < SE_SPEC_OF; ++i) {
-              const size_t vi = qe[i] ? se_voxel_index(qe[i], qi[i][0], qi[i][1], qi[i][2]) : 0;
-              qx[i] = m.vx[vi]; qy[i] = m.vy[vi];
-            }
-            bool stop = false;
-#pragma unroll
-            for (int i = 0; i < SE_SPEC_OF; ++i) {
-              if (stop) continue;
-              t = tt[i];
-              if (!(t < tfar)) { done = true; stop = true; continue; }
-              if (STATS) ++n_get;
-              const float dx = qe[i] ? qx[i] : fc.init_x, dy = qe[i] ? qy[i] : fc.init_y;
-              if (dx > -100.f && dy > 0.f) {
-                c.bx = qi[i][0] >> 3; c.by = qi[i][1] >> 3; c.bz = qi[i][2] >> 3; c.e = qe[i];
-                f_tt = se_interp<DENSE>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
-                if (STATS) ++n_interp;
-              }
-              if (f_tt > 0.f) { done = true; stop = true; continue; }
-              f_t = f_tt;
-            }
-            if (!stop) t = tt[SE_SPEC_OF - 1] + stepsize;
-          }
-          if (f_tt > 0.f) {
-            t = t - stepsize * (f_tt - 0.f) / (f_tt - f_t);
-            const f3 r = f3_add(org, f3_scale_r(dir, t));
-            hx = r.x; hy = r.y; hz = r.z; hw = t;
-          }
-        }
-      }
-    }
-  }
+  if (!OFUSION && DENSE) se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+  else if (OFUSION && DENSE) se_cast_ray_of_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+  else if (!OFUSION) se_cast_ray_sdf_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+  else se_cast_ray_of_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+}
+
+// ---- beam start (r05) ------------------------------------------------------------------------------------------------------------
+// Every ray used to begin its first-leaf search at the near plane and walk ~20 octree cells of empty space to the surface (19.7 trips per ray at
+// 512^3, ~45 % of the kernel's vector instructions).  The 64 rays of a wave form a thin beam (an 8x8 pixel tile: 5 cm across at 4 m), so the wave
+// first asks, cooperatively, how far the WHOLE beam is clear: lane i tests the point at t_i = near + i dt on the tile's centre ray against cbits,
+// the coarse bitmap in which every cell within one cell of an allocated block is set (se_device.h).  A clear bit at p means: no block within
+// `cell` (infinity norm) of p.  Every point of every ray of the tile with t in [t_i - dt/2, t_i + dt/2] lies within
+//     (t_i + dt/2) (rmax + eps) + dt/2
+// of p -- rmax = the largest distance between a ray's unit direction and the centre ray's (over the wave's 64 lanes, +5 %), eps the iterator's
+// clamp of near-zero direction components (ray_iterator.hpp:63-75: the traversed line differs from the true one by at most eps t) -- and the
+// sample counts as clear only if that bound is below 0.9 cell.  t_safe = the end of the clear run from the near plane; the rays enter the tree there
+// (se_first_leaf_lite).  Conservative by construction: centimetres of margin against rounding, a bit set concurrently by the next frame's scan
+// only shortens the run, NaN anywhere fails the bound -> no jump.
+__device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a, f3 org, f3 dir, float tile_cx, float tile_cy) {
+  const f3 dc = f3_normalized(m3_mul(a.view3, {tile_cx, tile_cy, 1.f}));
+  float dev = sqrtf(f3_sqnorm(f3_sub(dir, dc)));
+  for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
+  const float rad = dev * 1.05f + a.epsilon;
+  const int lane = threadIdx.x & 63;
+  const float ti = a.nearp + (float)lane * a.beam_dt;
+  const f3 p = f3_add(org, f3_scale_r(dc, ti));
+  const int C = m.clevel;
+  const int cx = se_cvt_flr(p.x * a.beam_inv_cell), cy = se_cvt_flr(p.y * a.beam_inv_cell), cz = se_cvt_flr(p.z * a.beam_inv_cell);
+  const bool in = (uint32_t)(cx | cy | cz) < (1u << C);     // outside the volume: no blocks there
+  const uint32_t idx = in ? (((uint32_t)cz << (2 * C)) | ((uint32_t)cy << C) | (uint32_t)cx) : 0u;
+  const uint32_t w = m.cbits[idx >> 5];
+  const bool occupied = in && ((w >> (idx & 31u)) & 1u);
+  const bool clear = !occupied && ((ti + 0.5f * a.beam_dt) * rad + 0.5f * a.beam_dt <= 0.9f * a.beam_cell);
+  const unsigned long long blocked = __ballot(!clear);
+  const int j = blocked ? (int)__builtin_ctzll(blocked) : 64;
+  if (j < 1) return 0.f;
+  return (a.nearp + ((float)j - 0.5f) * a.beam_dt) * a.inv_dim;
 }
 
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
@@ -2483,16 +2114,13 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     if (STATS) tk1 = __builtin_amdgcn_s_memtime();
   };
   // every thread of the workgroup goes through the set-up and the barrier; only rays inside the image enter the loop
-#if SE_FIRST_LEAF_LITE
   bool redo = false;
-  RaySpan span = se_first_leaf_lite<SHALLOW>(m, a, org, dir, s_occ, redo, finish_staging, in_image);
+  const float t_start = a.beam ? se_beam_start(m, a, org, dir, (float)(tx * SE_TILE_W) + 0.5f * (SE_TILE_W - 1), (float)(a.row_begin + ty * SE_TILE_H) + 0.5f * (SE_TILE_H - 1)) : 0.f;
+  RaySpan span = se_first_leaf_lite<SHALLOW>(m, a, org, dir, s_occ, redo, finish_staging, in_image, t_start);
   if (__any(redo)) {   // (about one ray in 10^6, plus rays that miss the volume: the reference iterator with its stack)
     const RaySpan full = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax, SeNoHook(), redo);
     if (redo) span = {full.tcmin, full.tmax, span.trips + full.trips};
   }
-#else
-  const RaySpan span = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax, finish_staging, in_image);
-#endif
   if (in_image) {
     const float t_min = span.tcmin, tfar = span.tmax;
     if (STATS) tk2 = __builtin_amdgcn_s_memtime();
@@ -2520,7 +2148,7 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     } else if (hw > 0.f) {   // (hit.w() > 0.0)
       if (STATS) { ++n_hit; ++n_grad; }
       v[0] = hx; v[1] = hy; v[2] = hz;
-      const f3 g = (SE_MARCH_LEAN && DENSE) ? se_grad_lean<O32>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c) : se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
+      const f3 g = DENSE ? se_grad_lean<O32>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c) : se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
       const f3 surfNorm = f3_scale(a.grad_scale, g);
       if (sqrtf(f3_sqnorm(surfNorm)) == 0) {
         n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;  // INVALID (commons.h:71)

@@ -19,6 +19,12 @@
 //     the first descent below the same parent).
 // The test runs every pixel of a few frames through both and requires bit-identical t_min (leaf found or not) for all
 // rays that are neither flagged nor irregular, and reports how many are.
+//
+// r05, beam start (se_beam_start / the t_start argument of se_first_leaf_lite): the 64 rays of an 8x8 pixel tile enter the tree at
+// t_start = the distance up to which a dilated coarse occupancy bitmap shows the whole beam clear, instead of at the near plane.  The model
+// restates that pre-pass in the kernel's own float arithmetic (beam_start below: same sample points, same bound, same 27-neighbourhood
+// dilation of the allocated blocks) and runs `lite` from there; fl_compare(..., beam = 1) then requires the same bit-identical t_min /
+// found decision against the iterator started at the near plane, and reports how many trips the jump saves.
 #include "../../oracle/se_oracle.cpp"
 
 namespace fl {
@@ -35,7 +41,7 @@ template <typename VT> static Node<VT>* node_at(const Octree<VT>& m, V3f pos, in
   return n;
 }
 
-template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f direction, float nearP, float farP) {
+template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f direction, float nearP, float farP, float t_start = 0.f) {
   Result r = {0.f, 0, 0, 0, 0};
   V3f pos = {1.f, 1.f, 1.f};
   int scale = CAST_STACK_DEPTH - 1;
@@ -58,6 +64,8 @@ template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f d
   t_min = fmaxf(t_min, nearP / m.dim_);
   const float t_lim = fminf(h0, farP / m.dim_);   // t_max_init: the only t_max the model knows
   if (!(t_min < h0)) { r.irregular = 1; r.t_min = t_min; return r; }
+  const bool jumped = t_start > t_min;
+  if (jumped) t_min = t_start;
   if (1.5f * tc.x - tb.x > t_min) pos.x = 1.5f;
   if (1.5f * tc.y - tb.y > t_min) pos.y = 1.5f;
   if (1.5f * tc.z - tb.z > t_min) pos.z = 1.5f;
@@ -99,13 +107,71 @@ template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f d
       }
     }
   }
+  if (jumped && t_min == t_start && !r.flagged) r.flagged = 1;   // never advanced: would return t_start as an entry time -> handed back
   r.t_min = t_min;
   return r;
 }
 
-template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad) {
+// the dilated coarse bitmap of se_device.h (DevMap::cbits), built from the oracle's block pool
+template <typename VT> static std::vector<uint32_t> coarse_bits(const Octree<VT>& m, int C) {
+  const int leaf_level = m.max_level_ - 3, sh = leaf_level - C, n = 1 << C;
+  std::vector<uint32_t> bits(std::max<size_t>(1, ((size_t)1 << (3 * C)) / 32), 0u);
+  for (size_t i = 0; i < m.block_buffer_.size(); ++i) {
+    const V3i c = m.block_buffer_[i]->coordinates_;
+    const int cx = (c.x >> 3) >> sh, cy = (c.y >> 3) >> sh, cz = (c.z >> 3) >> sh;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int ux = cx + dx, uy = cy + dy, uz = cz + dz;
+          if ((unsigned)ux >= (unsigned)n || (unsigned)uy >= (unsigned)n || (unsigned)uz >= (unsigned)n) continue;
+          const uint32_t idx = ((uint32_t)uz << (2 * C)) | ((uint32_t)uy << C) | (uint32_t)ux;
+          bits[idx >> 5] |= 1u << (idx & 31u);
+        }
+  }
+  return bits;
+}
+// se_beam_start of se_kernels.h for the tile whose first pixel is (x0, y0): the 64 "lanes" are the tile's pixels
+template <typename VT> static float beam_start(const Octree<VT>& m, const std::vector<uint32_t>& cbits, int C, const M4& view, int x0, int y0, float nearP, float farP) {
+  const V3f org = {view.m[0][3], view.m[1][3], view.m[2][3]};
+  const V3f dc = normalized(mul3(top3(view), {(float)x0 + 3.5f, (float)y0 + 3.5f, 1.f}));
+  float dev = 0.f;
+  for (int l = 0; l < 64; ++l) {
+    const V3f dir = normalized(mul3(top3(view), {(float)(x0 + (l & 7)), (float)(y0 + (l >> 3)), 1.f}));
+    const V3f d = dir - dc;
+    dev = fmaxf(dev, sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z));
+  }
+  const float epsilon = exp2f(-(float)std::log2((double)m.size_));
+  const float rad = dev * 1.05f + epsilon;
+  const float cell = m.dim_ / (float)(1 << C), inv_cell = (float)(1 << C) / m.dim_, inv_dim = 1.f / m.dim_;
+  const float dt = std::max(0.5f * cell, (farP - nearP) / 64.f);
+  int j = 64;
+  for (int l = 0; l < 64; ++l) {
+    const float ti = nearP + (float)l * dt;
+    const V3f p = org + dc * ti;
+    const int cx = (int)floorf(p.x * inv_cell), cy = (int)floorf(p.y * inv_cell), cz = (int)floorf(p.z * inv_cell);
+    const bool in = (uint32_t)(cx | cy | cz) < (1u << C);
+    const uint32_t idx = in ? (((uint32_t)cz << (2 * C)) | ((uint32_t)cy << C) | (uint32_t)cx) : 0u;
+    const bool occupied = in && ((cbits[idx >> 5] >> (idx & 31u)) & 1u);
+    const bool clear = !occupied && ((ti + 0.5f * dt) * rad + 0.5f * dt <= 0.9f * cell);
+    if (!clear) { j = l; break; }
+  }
+  if (j < 1) return 0.f;
+  return (nearP + ((float)j - 0.5f) * dt) * inv_dim;
+}
+
+template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad, int beam) {
   const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
   const Octree<VT>& oct = p->oct;
+  const int C = std::min(oct.max_level_ - 3, 5);
+  std::vector<uint32_t> cbits;
+  std::vector<float> tile_start;
+  const int tiles_x = (p->W + 7) / 8, tiles_y = (p->H + 7) / 8;
+  if (beam) {
+    cbits = coarse_bits(oct, C);
+    tile_start.resize((size_t)tiles_x * tiles_y);
+    for (int ty = 0; ty < tiles_y; ++ty)
+      for (int tx = 0; tx < tiles_x; ++tx) tile_start[(size_t)ty * tiles_x + tx] = beam_start(oct, cbits, C, view, tx * 8, ty * 8, nearPlane, farPlane);
+  }
   int64_t rays = 0, irregular = 0, flagged = 0, mismatch = 0, found = 0, trips_ref = 0, trips_lite = 0, model_bug = 0;
   int bad_x = -1, bad_y = -1;
 #pragma omp parallel for reduction(+ : rays, irregular, flagged, mismatch, found, trips_ref, trips_lite, model_bug)
@@ -118,7 +184,7 @@ template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm
       const bool ref_found = ray.next() != nullptr;
       const float ref_t = ray.t_min_;
       trips_ref += g_ray_iter;
-      const Result r = lite(oct, transl, dir, nearPlane, farPlane);
+      const Result r = lite(oct, transl, dir, nearPlane, farPlane, beam ? tile_start[(size_t)(y / 8) * tiles_x + x / 8] : 0.f);
       ++rays;
       trips_lite += r.trips;
       if (r.irregular) { ++irregular; continue; }
@@ -137,8 +203,8 @@ template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm
 
 }  // namespace fl
 
-extern "C" void fl_compare(void* pipe, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad) {
+extern "C" void fl_compare(void* pipe, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad, int beam) {
   PipelineBase* b = (PipelineBase*)pipe;
-  if (auto* s = dynamic_cast<Pipeline<SDFv>*>(b)) fl::compare(s, pose_cm, k, out, first_bad);
-  else if (auto* o = dynamic_cast<Pipeline<OFv>*>(b)) fl::compare(o, pose_cm, k, out, first_bad);
+  if (auto* s = dynamic_cast<Pipeline<SDFv>*>(b)) fl::compare(s, pose_cm, k, out, first_bad, beam);
+  else if (auto* o = dynamic_cast<Pipeline<OFv>*>(b)) fl::compare(o, pose_cm, k, out, first_bad, beam);
 }

@@ -24,11 +24,11 @@ def lib(tmp_path_factory):
                     "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "cpp", "first_leaf_equiv.cpp")], check=True, capture_output=True)
     lib = binding._declare(C.CDLL(so))
     lib.fl_compare.restype = None
-    lib.fl_compare.argtypes = [C.c_void_p, binding.c_f32p, binding.c_f32p, np.ctypeslib.ndpointer(np.int64), np.ctypeslib.ndpointer(np.int32)]
+    lib.fl_compare.argtypes = [C.c_void_p, binding.c_f32p, binding.c_f32p, np.ctypeslib.ndpointer(np.int64), np.ctypeslib.ndpointer(np.int32), C.c_int]
     return lib
 
 
-def _run(lib, field, kind, W, H, N, mu, frames, pose_shift=None):
+def _run(lib, field, kind, W, H, N, mu, frames, pose_shift=None, beam=0, first_view=3):
     st = make_stream(kind, W, H, 4.8)
     h = lib.so_pipe_create(field, N, 4.8, W, H)
     tot = np.zeros(8, np.int64)
@@ -38,13 +38,13 @@ def _run(lib, field, kind, W, H, N, mu, frames, pose_shift=None):
             pose = st.pose(f)
             k = np.asarray(st.k, np.float32)
             lib.so_pipe_integrate(h, d, to_colmajor(pose), k, 1, mu, f)
-            if f > 2:
+            if f >= first_view:
                 view = pose.copy()
                 if pose_shift is not None:
                     view[:3, 3] += np.asarray(pose_shift, np.float32)
                 out = np.zeros(8, np.int64)
                 bad = np.zeros(2, np.int32)
-                lib.fl_compare(h, to_colmajor(view), k, out, bad)
+                lib.fl_compare(h, to_colmajor(view), k, out, bad, beam)
                 assert out[3] == 0 and out[7] == 0, f"frame {f}: {out[3]} rays differ from the iterator (e.g. pixel {bad.tolist()}), model errors {out[7]}"
                 tot += out
     finally:
@@ -66,4 +66,30 @@ def test_rays_that_miss_the_volume_are_handed_back(lib):
     # camera pulled 6 m out of the 4.8 m volume: most rays enter through a face (regular), the rest miss it (irregular set-up);
     # both kinds must agree with the iterator or be handed back
     r = _run(lib, binding.SDF, "room", 160, 120, 256, 0.1, 5, pose_shift=(0.0, 0.0, -6.0))
+    assert r["irregular"] > 0 and r["mismatch"] == 0
+
+
+@pytest.mark.parametrize("field,kind,W,H,N,mu,frames,first_view", [
+    (binding.SDF, "room", 640, 480, 512, 0.1, 6, 3),         # the benchmark's geometry
+    (binding.SDF, "stress", 320, 240, 512, 0.1, 40, 30),     # the pan: occluders, depth edges, the volume's faces, rays that leave the cube
+    (binding.SDF, "stress", 320, 240, 1024, 0.1, 8, 4),
+    (binding.OFUSION, "stress", 320, 240, 512, 0.02, 8, 4),  # coarse childless octants in the tree (not blocks: they never stop the search)
+    (binding.SDF, "room", 160, 120, 128, 0.1, 6, 3),         # leaf level 4 < 5: the coarse grid IS the block grid
+])
+def test_beam_start_returns_the_iterators_leaf(lib, field, kind, W, H, N, mu, frames, first_view):
+    """r05: with every 8x8 tile's rays entering the tree at the tile's t_safe (se_beam_start, restated in tests/cpp/first_leaf_equiv.cpp), the
+    first leaf and its entry time are bit for bit those of the reference iterator started at the near plane, for every ray that is not handed
+    back -- and the search takes fewer than half the trips."""
+    base = _run(lib, field, kind, W, H, N, mu, frames, first_view=first_view)
+    r = _run(lib, field, kind, W, H, N, mu, frames, beam=1, first_view=first_view)
+    print(W, H, N, "trips per ray:", round(base["trips_lite"] / base["rays"], 2), "->", round(r["trips_lite"] / r["rays"], 2), "handed back:", r["flagged"], "of", r["rays"])
+    assert r["rays"] == base["rays"] and r["mismatch"] == 0 and r["model_bug"] == 0
+    assert r["found"] + r["flagged"] >= base["found"]              # (a handed-back ray is not counted as found)
+    assert r["flagged"] <= base["flagged"] + r["rays"] // 5000
+    if N >= 512:
+        assert r["trips_lite"] < 0.62 * base["trips_lite"]
+
+
+def test_beam_start_from_outside_the_volume(lib):
+    r = _run(lib, binding.SDF, "room", 160, 120, 256, 0.1, 5, pose_shift=(0.0, 0.0, -6.0), beam=1)
     assert r["irregular"] > 0 and r["mismatch"] == 0

@@ -3,7 +3,7 @@
 workload, one subprocess runs a pipelined stream from device-resident depth frames and prints
   fps (wall clock, no events), per-kernel averages (HIP events, second pass on a fresh map), stand-alone raycast time,
   and a SHA-1 over the final map + raycast images -- every build must print the same hash (results are bit-identical).
-usage: lib_ab.py [--cfgs sdf512,sdf1024,...] [--frames N] name1 name2 ..."""
+usage: lib_ab.py [--cfgs sdf512,sdf1024,...] [--frames N] name1 name2 ...      (name = library[@ENV=VALUE...])"""
 import hashlib
 import json
 import os
@@ -128,8 +128,12 @@ if __name__ == "__main__":
         for name in a:
             env = dict(os.environ)
             env.pop("SE_HIP_LIB", None)
-            if name != "default":
-                env["SE_HIP_LIB"] = os.path.join(ROOT, "gpurun_ab", name + ".so")
+            lib_name, *knobs = name.split("@")          # "default@SE_HIP_IEEE_SWEEP=1": a library plus environment knobs
+            for kv in knobs:
+                kk, _, vv = kv.partition("=")
+                env[kk] = vv
+            if lib_name != "default":
+                env["SE_HIP_LIB"] = os.path.join(ROOT, "gpurun_ab", lib_name + ".so")
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", cfg, str(n)], env=env, capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if not line:
