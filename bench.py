@@ -295,7 +295,7 @@ def extra_modes(args, field, depth_ptrs, poses, k, warm, n, device):
     return out
 
 
-def cpp_mirror_leg(args, stream, warm: int, n: int):
+def cpp_mirror_leg(args, k, host_depth, poses, warm: int, n: int):
     """The drop-in surface itself: examples/denseslam_bench.cpp runs the loop of se_apps/src/benchmark.cpp:115-177 through the C++
     DenseSLAMSystem mirror (include/se/DenseSLAMSystem.h: preprocessing / setPose / integration / raycasting / synchroniseDevices) on the same
     frames, in its own process (no Python in the loop), and reports frames/s closed-loop (the reference's bracketing), streaming (the one-queue
@@ -309,10 +309,10 @@ def cpp_mirror_leg(args, stream, warm: int, n: int):
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as fh:
         path = fh.name
         np.asarray([args.width, args.height, F], np.int32).tofile(fh)
-        np.asarray(stream.k, np.float32).reshape(4).tofile(fh)
+        np.asarray(k, np.float32).reshape(4).tofile(fh)
         for f in range(F):
-            np.ascontiguousarray(stream.pose(f), np.float32).reshape(16).tofile(fh)
-            np.ascontiguousarray(stream.depth(f), np.float32).reshape(-1).tofile(fh)
+            np.ascontiguousarray(poses[f], np.float32).reshape(16).tofile(fh)
+            np.ascontiguousarray(host_depth[f], np.float32).reshape(-1).tofile(fh)
     try:
         r = subprocess.run([exe, path, str(args.res), str(args.dim), str(args.mu), str(warm), str(n)], capture_output=True, text=True, timeout=300)
     finally:
@@ -719,7 +719,7 @@ def main():
         result["value_note"] = ("value = K pipelined frames / wall time (poses known in advance: scan(f+1) runs beside raycast(f)); "
                                 "value_closed_loop = the same K frames with a device sync after every frame, SURVEY 8(d)'s bracketing")
     if rank == 0 and world == 1 and not args.no_modes and field == SDF and not args.raw:
-        cm = cpp_mirror_leg(args, stream, warm, min(K, F - warm))
+        cm = cpp_mirror_leg(args, k, host_depth, poses, warm, min(K, F - warm))
         result["cpp_mirror"] = cm
         if "streaming_fps" in cm:
             result["value_cpp_mirror"] = cm["streaming_fps"]

@@ -356,15 +356,17 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_commit(DevMap m, const unsigned
 // of frame f it inserts into tab[] / the lists but leaves occ[] (which that raycast is walking)
 // alone; this kernel then sets the bits of every inserted octant and of all its ancestors.
 struct OccLists { const unsigned long long* lists; int nlists; long long stride_words; };   // [count, keys...] per list
-// Done by the first `nwg` workgroups of the launch only: every participating thread reads each list's count word first
-// (nlists dependent round trips), which the ~10^4 other waves of a sweep launch need not pay for.
-__device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L, unsigned nwg) {
-  if (blockIdx.x >= nwg) return;
+// Done by `nwg` workgroups of the launch only, those from index `first` on: every participating thread reads each list's count word first
+// (nlists dependent round trips), which the ~10^4 other waves of a sweep launch need not pay for -- and which workgroup 0 of a sweep, whose
+// raycast scheduler is the longest dependent chain of the launch, must not have in front of it (first = 1 there: r05, 6-10 us on the stress stream).
+__device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L, unsigned nwg, unsigned first = 0u) {
+  if (blockIdx.x < first || blockIdx.x >= first + nwg) return;
+  const unsigned wg = blockIdx.x - first;
   for (int li = 0; li < L.nlists; ++li) {
     const unsigned long long* list = L.lists + (long long)li * L.stride_words;
     unsigned long long n = list[0];
     if (n > (unsigned long long)(L.stride_words - 1)) n = (unsigned long long)(L.stride_words - 1);
-    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)nwg * blockDim.x) {
+    for (unsigned long long i = wg * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)nwg * blockDim.x) {
       const unsigned long long raw = list[1 + i];
       if (raw & SE_KEY_ACTIVATE) continue;
       const int level = (int)(raw & 0x1FFull);
@@ -486,85 +488,89 @@ struct IntegArgs {
 };
 
 // One workgroup turns the previous raycast's per-tile costs into the schedule of the next one:
-//  * 256-bin histogram -> priority thresholds = smallest cost v with #(cost >= v) <= fraction * n;
-//  * counting sort of the tile pairs (tiles 2p, 2p+1: the two waves of one raycast workgroup) by their mean cost ->
-//    order[] = pairs, costliest first (ties in arrival order: scheduling only, never results).
-// cost[] is padded (16-byte loads); hist = 784 words of LDS.
+//  * 256-bin histogram of the tile pairs (tiles 2p, 2p+1: the two waves of one raycast workgroup) by their mean cost;
+//  * priority thresholds = smallest cost v with #(pairs of mean cost >= v) <= fraction * pairs;
+//  * counting sort of the pairs -> order[] = pairs, costliest first (ties in arrival order: scheduling only, never results).
+// The function is the critical path of a small sweep launch (it runs in workgroup 0 while the others sweep blocks: r01-r04 it was ~22 us of dependent
+// round trips, longer than a 512^3 sweep's blocks), so it is built for latency: the costs are loaded once, all loads of a thread issued together, and
+// kept in registers for both passes; one LDS atomic per pair and pass; a chunk of 8 neighbouring tiles goes to a lane far from the lanes that get the
+// chunks around it (neighbouring tiles have near-equal costs, and 64 lanes adding to one LDS word are served one after the other); the suffix sums over
+// the bins are one bin per thread.  cost[] is padded (16-byte loads); hist = 784 words of LDS.
 __device__ __forceinline__ void se_ray_schedule(const unsigned short* __restrict__ cost, int n, int* __restrict__ thr, unsigned* hist, const int* permille,
                                                 uint32_t* __restrict__ order) {
   static_assert(SE_WG == 256, "se_ray_schedule: one histogram bin per thread");
+  // this workgroup's four waves are a chain of short dependent steps; the block-sweeping waves they share their SIMDs with have arithmetic to issue
+  // at every cycle -- at equal priority each step of the chain queues behind them
+  __builtin_amdgcn_s_setprio(3);
   unsigned* phist = hist + 256;   // pairs per mean cost
   unsigned* base = hist + 512;    // first slot of each cost in order[]
-  unsigned* wsum = hist + 768;    // [2][4] wave totals of the suffix sums
+  unsigned* wsum = hist + 768;    // [4] wave totals of the suffix sums
   int* tmin = (int*)(hist + 776); // [3] thresholds
   const unsigned tid = threadIdx.x;
-  // The costs, 8 tiles (one 16-byte load) per chunk, chunk c of thread t = t + 256 c: every thread's loads are issued together and stay in registers
-  // for both passes (r05: the function is the critical path of a 512^3 sweep launch -- it was ~20 us of dependent round trips, see k_integrate).
-  // CH chunks per thread cover 20 480 tiles (1280x960: 19 200); tiles beyond that keep the image-order schedule (order[] = identity there).
+  // CH chunks of 8 tiles per thread cover 20 480 tiles (1280x960: 19 200); tiles beyond that keep the image-order schedule (order[] = identity there)
   constexpr int CH = 10;
-  const int nch = (n + 7) >> 3;
+  const int nch = min((n + 7) >> 3, CH * 256);
+  const int n_pairs = (n + 1) >> 1;
+  // chunk of work item i = i * S mod nch, S a prime that does not divide nch (a bijection of 0 .. nch - 1)
+  const int S = (nch % 37) ? 37 : ((nch % 41) ? 41 : 43);
   uint4 q[CH];
+  int ck[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
-    const int c = (int)tid + 256 * j;
-    q[j] = c < nch ? *(const uint4*)(cost + 8 * c) : make_uint4(0u, 0u, 0u, 0u);
+    const int i = (int)tid + 256 * j;
+    ck[j] = i < nch ? (int)(((long long)i * S) % nch) : -1;
+    q[j] = ck[j] >= 0 ? *(const uint4*)(cost + 8 * ck[j]) : make_uint4(0u, 0u, 0u, 0u);
   }
-  hist[tid] = 0u; phist[tid] = 0u;
+  phist[tid] = 0u;
   if (tid < 3u) tmin[tid] = 256;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < CH; ++j) {
-    const int c = (int)tid + 256 * j;
-    if (c >= nch) continue;
+    if (ck[j] < 0) continue;
     const unsigned w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int t0 = 8 * c + 2 * e;
+      const int t0 = 8 * ck[j] + 2 * e;
       if (t0 >= n) continue;
-      const unsigned c0 = w[e] & 0xFFFFu, c1 = (t0 + 1 < n) ? (w[e] >> 16) : 0u;
-      atomicAdd(&hist[min(c0, 255u)], 1u);
-      if (t0 + 1 < n) atomicAdd(&hist[min(c1, 255u)], 1u);
+      const unsigned c0 = w[e] & 0xFFFFu, c1 = (t0 + 1 < n) ? (w[e] >> 16) : c0;
       atomicAdd(&phist[min((c0 + c1) >> 1, 255u)], 1u);
     }
   }
   __syncthreads();
-  // Suffix sums over the 256 bins, one bin per thread: acc = #(tiles with cost >= v), base[v] = #(pairs with a higher mean cost than v).
-  // Threshold k = the smallest v >= 1 with acc(v) <= lim[k] (acc falls as v rises), 256 if there is none.
+  // suffix sums over the 256 bins, one bin per thread: b = #(pairs with mean cost >= v)
   const unsigned ln = tid & 63u, wv = tid >> 6;
   const unsigned ph = phist[tid];
-  unsigned a = hist[tid], b = ph;
+  unsigned b = ph;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const unsigned ua = __shfl_down(a, o), ub = __shfl_down(b, o);
-    if (ln + o < 64u) { a += ua; b += ub; }
+    const unsigned ub = __shfl_down(b, o);
+    if (ln + o < 64u) b += ub;
   }
-  if (ln == 0u) { wsum[wv] = a; wsum[4 + wv] = b; }
+  if (ln == 0u) wsum[wv] = b;
   __syncthreads();
-  for (unsigned w2 = wv + 1; w2 < 4u; ++w2) { a += wsum[w2]; b += wsum[4 + w2]; }
+  for (unsigned w2 = wv + 1; w2 < 4u; ++w2) b += wsum[w2];
   base[tid] = b - ph;
   if (tid >= 1u) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const unsigned lim = (unsigned)((long long)n * permille[k] / 1000);
-      if (a <= lim) atomicMin(&tmin[k], (int)tid);
+      const unsigned lim = (unsigned)((long long)n_pairs * permille[k] / 1000);
+      if (b <= lim) atomicMin(&tmin[k], (int)tid);
     }
   }
   __syncthreads();
   if (tid < 3u) thr[tid] = tmin[tid];
   if (order) {
-    // counting sort of the pairs by mean cost, costliest first (ties in arrival order: scheduling only, never results)
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int c = (int)tid + 256 * j;
-      if (c >= nch) continue;
+      if (ck[j] < 0) continue;
       const unsigned w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int t0 = 8 * c + 2 * e;
+        const int t0 = 8 * ck[j] + 2 * e;
         if (t0 >= n) continue;
-        const unsigned c0 = w[e] & 0xFFFFu, c1 = (t0 + 1 < n) ? (w[e] >> 16) : 0u;
+        const unsigned c0 = w[e] & 0xFFFFu, c1 = (t0 + 1 < n) ? (w[e] >> 16) : c0;
         const unsigned cc = min((c0 + c1) >> 1, 255u);
-        order[base[cc] + atomicSub(&phist[cc], 1u) - 1u] = (uint32_t)(4 * c + e);   // phist[cc] counts down: a unique slot of cc's range
+        order[base[cc] + atomicSub(&phist[cc], 1u) - 1u] = (uint32_t)(4 * ck[j] + e);   // phist[cc] counts down: a unique slot of cc's range
       }
     }
   }
@@ -795,15 +801,24 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
   unsigned long long swept = 0;
   // counters as this sweep sees them -> pinned host memory (posted write; sizes the next sweep's grid
   // without a device-to-host copy between this kernel and the raycast)
-  if (a.ctr_mirror && blockIdx.x == 0 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
-  if (a.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_count = 0ull;
-  if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x, 64u));   // nothing in this kernel reads occ[]; the raycast that follows does
+  // (by the LAST workgroup: workgroup 0 runs the raycast scheduler below, whose loads would queue up behind the acknowledgement of a store that
+  // crosses PCIe)
+  if (a.ctr_mirror && blockIdx.x == gridDim.x - 1 && threadIdx.x < C_COUNT) a.ctr_mirror[threadIdx.x] = m.ctr[threadIdx.x];
+  if (a.zero_count && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *a.zero_count = 0ull;
   __shared__ unsigned s_hist[784];
   // workgroup 0 computes the next raycast's schedule and therefore takes no blocks -- with its share of them on top it was the last workgroup of
   // the launch to finish.  (r01-r04 it WAS the launch: ~22 us of dependent round trips in se_ray_schedule under a 512^3 sweep whose blocks take 18-21 us)
   const bool scheduler = a.prio_thr != nullptr && gridDim.x > 1;
   const int wskip = scheduler ? SE_WG / 64 : 0;
+  if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x - (scheduler ? 1u : 0u), 64u), scheduler ? 1u : 0u);   // nothing in this kernel reads occ[]; the raycast that follows does
+#ifdef SE_SCHED_TIMING
+  const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) atomicMax(&m.stats[12], ~rt_in);   // (the stats words start at zero: max of the complement = min)
+#endif
   if (scheduler && blockIdx.x == 0) se_ray_schedule(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille, a.ray_order);
+#ifdef SE_SCHED_TIMING
+  if (scheduler && blockIdx.x == 0 && threadIdx.x == 0) { m.stats[13] = rt_in; m.stats[14] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   const SeRcp rmu = se_rcp_refined(a.mu);   // (FAST, SDF: the divisor-only part of diff / mu, once per wave)
   // (the block position of the next iteration is loaded an iteration ahead, and the first one beside the counters rather than behind them: in bounds
   // whatever the counter says.  Voxel loads in front of the active test -- one dependent round trip less per block -- measured +-0 at 512^3, -3 % at
@@ -918,6 +933,9 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     }
   }
   if (a.stats && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
+#ifdef SE_SCHED_TIMING
+  if (lane == 0 && !(scheduler && blockIdx.x == 0)) atomicMax(&m.stats[15], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
   for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG)
     se_update_node_corner<OFUSION>(m, depthmap, a, tid);
 }
