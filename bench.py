@@ -213,7 +213,7 @@ def freeze_gc():
 def prewarm(args, field, depth_ptrs, poses, k, device, ms: float = 90.0):
     """Untimed: keeps the GPU busy with the same kernels on a scratch map for `ms` milliseconds right before a timed
     region (the pipeline to be timed already exists by then): clocks, caches and code paths warm, so that the K timed steps
-    measure the steady state (frames run 78-81 us in the first ~20 ms of load after idle, 75-76 us ever after, tools/long_run.py).
+    measure the steady state (frames run 78-81 us in the first ~20 ms of load after idle, 75-76 us ever after, r03 long-run measurement).
     r02-r03 also credited this with hiding "the one 35-40 ms clock-ramp stall"; that stall is CPython's garbage collector
     (profiles/r04f_stall_attribution.md) and is dealt with where it belongs: freeze_gc() below."""
     from supereight_amd.pipeline import DenseSLAMPipeline

@@ -49,6 +49,8 @@ struct DevMap {
                                   // set for every cell within one cell (27-neighbourhood) of an allocated block: 4 KB at level 5.  A clear bit = no block anywhere
                                   // within one coarse cell of any point of this cell.  Only ever set (never cleared: blocks are never freed).
   int clevel;
+  uint32_t* fbits;                // the same at the block grid's own resolution (level leaf_level): set for every cell within one BLOCK of an allocated block;
+                                  // 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 (second stage of the beam start); null if leaf_level <= clevel
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)

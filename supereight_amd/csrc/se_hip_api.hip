@@ -151,8 +151,8 @@ struct se_hip_pipeline {
   DevMap map{};
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
-  size_t occ_words = 0, lbits_words = 0, cbits_words = 0;
-  bool beam = true;            // raycast: beam start (se_beam_start); SE_HIP_BEAM=0 switches it off (A/B knob: results are the same either way)
+  size_t occ_words = 0, lbits_words = 0, cbits_words = 0, fbits_words = 0;
+  int beam = 2;                // raycast: beam start (se_beam_start): 0 off, 1 coarse stage only, 2 both stages; SE_HIP_BEAM (A/B knob: results are the same either way)
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
@@ -199,11 +199,6 @@ struct se_hip_pipeline {
   int prio_permille[3] = {400, 150, 50}; // share of the tiles raised to priority >= 1 / >= 2 / 3 (SE_HIP_PRIO_SHARE="a,b,c", per mille)
   uint32_t* ray_order = nullptr;   // raycast schedule: the workgroups' tile pairs by descending previous cost (RayArgs::ray_order)
   int n_cus = 256;
-#ifdef SE_DIAG
-  uint32_t* diag_pix = nullptr;   // diagnostic build: per-pixel / per-wave raycast records (se_hip_diag_*)
-  uint32_t* diag_wave = nullptr;
-  int debug_integ = 0;
-#endif
 };
 
 namespace {
@@ -309,14 +304,6 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.epsilon = exp2f(-(float)p->max_level);  // ray_iterator.hpp:63
   a.min_scale = 23 - p->leaf_level;         // ray_iterator.hpp:62
   a.W = p->cfg.width; a.H = p->cfg.height; a.row_begin = p->row_begin; a.row_end = p->row_end;
-#ifdef SE_DIAG
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_ROWS")) {  // diagnostic build: raycast only rows [b,e)
-    int b = 0, e = 0;
-    if (std::sscanf(ev, "%d,%d", &b, &e) == 2 && b >= 0 && e > b && e <= a.H) { a.row_begin = b; a.row_end = e; }
-  }
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_RAY_PHASES")) a.debug_phases = std::atoi(ev);
-  a.diag_pix = p->diag_pix; a.diag_wave = p->diag_wave;
-#endif
   // occupancy levels staged in LDS: levels 1..5 (4.7 KB; measured: level 6 = +32 KB costs more
   // occupancy and staging time than the leaf-level bit tests it saves) unless overridden
   int cl = p->ray_cache_levels >= 0 ? p->ray_cache_levels : 5;
@@ -332,7 +319,17 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.cost_shift = std::max(0, p->leaf_level - 6);
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
   // beam start: 64 samples on a tile's centre ray, half a coarse cell apart (or whatever spacing covers near .. far)
-  a.beam = p->beam ? 1 : 0;
+  a.beam = (p->beam >= 2 && !m.fbits) ? 1 : p->beam;
+  a.beam_cellf = m.dim / (float)(1 << m.leaf_level);
+  a.beam_inv_cellf = (float)(1 << m.leaf_level) / m.dim;
+  a.beam_dt2 = 0.4f * a.beam_cellf;
+  if (a.beam >= 2) {
+    // the fine stage pays (one more dependent load per wave, of a bitmap that is 256 KB at 1024^3) only where its clearance bound can hold at working
+    // distance: an 8x8 pixel beam at 3/4 of the far plane must fit inside one block's margin (true at 512^3 / 640x480, not at 1024^3: measured +-0 there
+    // in the pipeline and +8 us on a stand-alone raycast, profiles/r05o_beam2_ab.log)
+    const float rad = 1.05f * std::hypot(0.5f * (SE_TILE_W - 1) / std::fabs(k[0]), 0.5f * (SE_TILE_H - 1) / std::fabs(k[1])) + a.epsilon;
+    if (!((0.75f * a.farp + 0.5f * a.beam_dt2) * rad + 0.5f * a.beam_dt2 <= 0.9f * a.beam_cellf)) a.beam = 1;
+  }
   a.beam_cell = m.dim / (float)(1 << m.clevel);
   a.beam_inv_cell = (float)(1 << m.clevel) / m.dim;
   a.beam_dt = std::max(0.5f * a.beam_cell, (a.farp - a.nearp) / 64.f);
@@ -442,6 +439,7 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.lbits, 0, p->lbits_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.cbits, 0, p->cbits_words * sizeof(uint32_t), p->stream);
+  if (m.fbits) hipMemsetAsync(m.fbits, 0, p->fbits_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
   hipMemsetAsync(m.npos, 0, p->cap_nodes * sizeof(uint32_t), p->stream);
@@ -495,11 +493,8 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_RAY_CACHE_LEVELS")) p->ray_cache_levels = std::atoi(ev);  // tuning knob
   if (const char* ev = std::getenv("SE_HIP_ICP_LOOKAHEAD")) p->icp_lookahead = std::max(0, std::atoi(ev));   // A/B knob (0: every ICP iteration enqueued up front)
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
-  if (const char* ev = std::getenv("SE_HIP_BEAM")) p->beam = std::atoi(ev) != 0;                   // A/B + test knob
+  if (const char* ev = std::getenv("SE_HIP_BEAM")) p->beam = std::max(0, std::min(2, std::atoi(ev)));   // A/B + test knob
   if (const char* ev = std::getenv("SE_HIP_IEEE_SWEEP")) p->ieee_sweep = std::atoi(ev) != 0;       // A/B + test knob: the sweep instantiation with the compiler's divisions
-#ifdef SE_DIAG
-  if (const char* ev = std::getenv("SE_HIP_DEBUG_INTEG")) p->debug_integ = std::atoi(ev);
-#endif
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
     int a = 0, b = 0, c = 0;
@@ -574,6 +569,8 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   m.clevel = std::min(p->leaf_level, 5);      // coarse cells of dim / 32 (15 cm at 4.8 m): see se_beam_start
   p->cbits_words = std::max<size_t>(1, ((size_t)1 << (3 * m.clevel)) / 32);
   ALLOC(m.cbits, p->cbits_words * sizeof(uint32_t));
+  m.fbits = nullptr;
+  if (p->leaf_level > m.clevel) { p->fbits_words = cells / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
   m.vy = m.vx + 512;
   ALLOC(m.bpos, cap * sizeof(uint32_t));
@@ -643,7 +640,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& t : p->pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
-  void* ptrs[] = {m.occ, m.lbits, m.cbits, m.tab, m.vx, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
+  void* ptrs[] = {m.occ, m.lbits, m.cbits, m.fbits, m.tab, m.vx, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
                   p->depth_own, p->depth_mm, p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
@@ -720,7 +717,7 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
 
 // host -> device through the pinned staging ring (see se_hip_pipeline::stage_host)
 int staged_upload(se_hip_pipeline* p, void* dev, const void* host, size_t bytes, hipStream_t s) {
-  // measured on MI355X / ROCm 7.2 (tools/pcie_rate.py): from 1 MB up the runtime's own pageable path (it pins
+  // measured on MI355X / ROCm 7.2 (r02 measurement): from 1 MB up the runtime's own pageable path (it pins
   // the pages and DMAs from them) beats a host-side copy into the ring; below that it blocks on the stream
   if (bytes >= ((size_t)1 << 20)) { HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s)); return SE_HIP_OK; }
   if (p->stage_cap < bytes) {
@@ -805,7 +802,10 @@ int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& s
   const int ray_wgs = (int)L.grid.x;
   const size_t smem = std::max(L.smem, (size_t)SE_SCAN_SLOTS * SE_WG_SCAN * sizeof(uint32_t));
   const dim3 grid((unsigned)(ray_wgs + scan_wgs)), block(SE_WG_RAY);
-  const int first_round = 10 * p->n_cus;   // workgroups of 2 waves the chip holds at once at 5 waves per SIMD (k_raycast_scan)
+  // workgroups of 2 waves the chip holds at once at 5 waves per SIMD (k_raycast_scan): the raycast's workgroups all start at once, the scan's follow.
+  // (r05, measured: letting scan workgroups in earlier -- the first 1 280 / 640 / 0 workgroups the raycast's, then alternating -- delays raycast waves and
+  // the launch ends later by 1 / 3 / 8 us at 512^3 SDF and 16 / 25 / 31 us for OFusion, profiles/r05p_fuse_first_ab.log)
+  const int first_round = 10 * p->n_cus;
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   const size_t nb = (size_t)(m.size >> 3);
   // (a dense grid of > 4 GiB with every level staged -- only with SE_HIP_RAY_CACHE_LEVELS raised -- takes the generic instantiation)
@@ -1045,9 +1045,6 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   const M4 pose = from_colmajor(pose_cm);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   IntegArgs a{};
-#ifdef SE_DIAG
-  a.debug = p->debug_integ;
-#endif
   a.commit_occ = p->occ_commit_due ? 1 : 0;
   a.occ_lists = p->occ_lists;
   p->occ_commit_due = false;
@@ -1968,28 +1965,5 @@ int se_hip_get_stats(se_hip_pipeline* p, uint64_t out[16], int32_t reset) {
   return SE_HIP_OK;
 }
 
-#ifdef SE_DIAG
-// Diagnostic build only (tools/): per-pixel and per-wave records of the STATS raycast variants.
-int se_hip_diag_enable(se_hip_pipeline* p, int32_t on) {
-  if (int r = check(p)) return r;
-  const size_t npix = (size_t)p->cfg.width * p->cfg.height, nwave = ((size_t)(p->cfg.width + 7) / 8) * ((size_t)(p->cfg.height + 7) / 8);
-  if (on && !p->diag_pix) {
-    HIP_TRY(hipMalloc((void**)&p->diag_pix, npix * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&p->diag_wave, nwave * 8 * sizeof(uint32_t)));
-  }
-  if (!on) { if (p->diag_pix) hipFree(p->diag_pix); if (p->diag_wave) hipFree(p->diag_wave); p->diag_pix = p->diag_wave = nullptr; }
-  if (p->diag_pix) { HIP_TRY(hipMemset(p->diag_pix, 0, npix * sizeof(uint32_t))); HIP_TRY(hipMemset(p->diag_wave, 0, nwave * 8 * sizeof(uint32_t))); }
-  return SE_HIP_OK;
-}
-int se_hip_diag_download(se_hip_pipeline* p, uint32_t* pix, uint32_t* wave) {
-  if (int r = check(p)) return r;
-  if (!p->diag_pix) return fail(SE_HIP_E_INVALID, "se_hip_diag_enable first");
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  const size_t npix = (size_t)p->cfg.width * p->cfg.height, nwave = ((size_t)(p->cfg.width + 7) / 8) * ((size_t)(p->cfg.height + 7) / 8);
-  if (pix) HIP_TRY(hipMemcpy(pix, p->diag_pix, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (wave) HIP_TRY(hipMemcpy(wave, p->diag_wave, nwave * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  return SE_HIP_OK;
-}
-#endif
 
 }  // extern "C"

@@ -51,23 +51,30 @@ __device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, 
 
 // Inserts the octant (x,y,z)@level (block if level == leaf_level, else an internal node with no
 // children yet) if absent.  Returns true if this thread created it.
-// A new block marks its coarse cell and the 26 around it in cbits (se_device.h): per (y, z) neighbour the three x-neighbours are adjacent bits of
-// one word (a row of 2^clevel <= 32 cells never straddles a word).  Read first: almost every bit is set already.
+// A new block marks its cell and the 26 around it in a dilated bitmap of level C (cbits: the coarse grid, fbits: the block grid itself; se_device.h).
+// (cx, cy, cz) = the block's cell at that level.  Read first: almost every bit is set already.
+// Per (y, z) neighbour the three x-neighbours are adjacent bits: one atomic OR, two where they straddle a word.  No read-before-write and nothing
+// that returns a value: the thread that inserts a block must not wait -- a first version that looked at each word first (27 dependent round trips in a
+// rolled loop) made the one inserting lane of a wave the last thing alive in the launch and doubled the allocation scan's duration.  A rolled loop
+// because the call sits in the rare insertion branch of the scans' unrolled flush code (eight copies).
+__device__ __forceinline__ void se_mark_dilated(uint32_t* bits, int C, int cx, int cy, int cz) {
+  const int n = 1 << C;
+  const int lo = max(cx - 1, 0), hi = min(cx + 1, n - 1);
+#pragma clang loop unroll(disable)
+  for (int k = 0; k < 9; ++k) {
+    const int uy = cy + (k % 3) - 1, uz = cz + (k / 3) - 1;
+    if ((unsigned)uy >= (unsigned)n || (unsigned)uz >= (unsigned)n) continue;
+    const uint32_t base = ((uint32_t)uz << (2 * C)) | ((uint32_t)uy << C);
+    const uint32_t i0 = base + (uint32_t)lo, i1 = base + (uint32_t)hi;
+    const unsigned long long run = ((1ull << (hi - lo + 1)) - 1ull) << (i0 & 31u);     // bits lo .. hi relative to word i0 >> 5
+    atomicOr(bits + (i0 >> 5), (uint32_t)run);
+    if ((i1 >> 5) != (i0 >> 5)) atomicOr(bits + (i1 >> 5), (uint32_t)(run >> 32));
+  }
+}
 __device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, int bz) {
-  const int C = m.clevel, sh = m.leaf_level - C, n = 1 << C;
-  const int cx = bx >> sh, cy = by >> sh, cz = bz >> sh;
-  const uint32_t row = (cx == 0 ? 3u : (7u << (cx - 1))) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
-#pragma unroll
-  for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int uy = cy + dy, uz = cz + dz;
-      if ((unsigned)uy >= (unsigned)n || (unsigned)uz >= (unsigned)n) continue;
-      const uint32_t base = ((uint32_t)uz << (2 * C)) | ((uint32_t)uy << C);
-      const uint32_t bits = row << (base & 31u);
-      uint32_t* w = m.cbits + (base >> 5);
-      if ((*(volatile uint32_t*)w & bits) != bits) atomicOr(w, bits);
-    }
+  const int sh = m.leaf_level - m.clevel;
+  se_mark_dilated(m.cbits, m.clevel, bx >> sh, by >> sh, bz >> sh);
+  if (m.fbits) se_mark_dilated(m.fbits, m.leaf_level, bx, by, bz);
 }
 
 __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int x, int y, int z) {
@@ -462,9 +469,6 @@ struct IntegArgs {
   int fast_div;            // the operands of the sweep's divisions are in the range in which their shared-reciprocal form is the IEEE division (see se_rcp_refined)
   int commit_occ;          // publish the occupancy bits of this frame's (side-stream) allocation scan / commit first
   OccLists occ_lists;      // the key lists whose insertions are published
-#ifdef SE_DIAG
-  int debug;               // diagnostic build only: 1 = no update arithmetic (copy voxels through), 2 = no voxel loads / stores
-#endif
   uint32_t* ctr_mirror;    // pinned host copy of ctr[] (launch-geometry estimate of the next sweep), may be null
   unsigned long long* zero_count;   // count word of the key list the NEXT allocation scan appends to (the handle's two own lists
                                     // alternate): cleared here, so that no fill kernel sits in front of that scan; may be null
@@ -811,14 +815,7 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
   const bool scheduler = a.prio_thr != nullptr && gridDim.x > 1;
   const int wskip = scheduler ? SE_WG / 64 : 0;
   if (a.commit_occ) se_occ_commit(m, a.occ_lists, min(gridDim.x - (scheduler ? 1u : 0u), 64u), scheduler ? 1u : 0u);   // nothing in this kernel reads occ[]; the raycast that follows does
-#ifdef SE_SCHED_TIMING
-  const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
-  if (lane == 0) atomicMax(&m.stats[12], ~rt_in);   // (the stats words start at zero: max of the complement = min)
-#endif
   if (scheduler && blockIdx.x == 0) se_ray_schedule(a.tile_cost, a.n_tiles, a.prio_thr, s_hist, a.prio_permille, a.ray_order);
-#ifdef SE_SCHED_TIMING
-  if (scheduler && blockIdx.x == 0 && threadIdx.x == 0) { m.stats[13] = rt_in; m.stats[14] = __builtin_amdgcn_s_memrealtime(); }
-#endif
   const SeRcp rmu = se_rcp_refined(a.mu);   // (FAST, SDF: the divisor-only part of diff / mu, once per wave)
   // (the block position of the next iteration is loaded an iteration ahead, and the first one beside the counters rather than behind them: in bounds
   // whatever the counter says.  Voxel loads in front of the active test -- one dependent round trip less per block -- measured +-0 at 512^3, -3 % at
@@ -839,23 +836,10 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     const unsigned char act = m.bactive[slot];
     if (!act && !se_in_frustum(a, bx, by, bz)) continue;
     if (a.stats && lane == 0) ++swept;
-#ifdef SE_DIAG
-    if (a.debug == 2) {
-#pragma unroll
-      for (int zi = 0; zi < 8; ++zi) { vx[zi] = 1.f; vy[zi] = (float)zi; }
-    } else
-#endif
     {
 #pragma unroll
       for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
     }
-#ifdef SE_DIAG
-    if (a.debug == 1) {
-#pragma unroll
-      for (int zi = 0; zi < 8; ++zi) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
-      continue;
-    }
-#endif
     bool visible = false;
     const int y = by + ly;
     // update_block (projective_functor.hpp:73-111)
@@ -903,9 +887,6 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
-#ifdef SE_DIAG
-      if (a.debug == 2) { if (vx[zi] == 12345.f) px[zi * 64] = vx[zi]; continue; }   // keep the arithmetic alive
-#endif
       if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
     }
     const bool any = __ballot(visible) != 0ull;
@@ -933,9 +914,6 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     }
   }
   if (a.stats && lane == 0 && swept) atomicAdd(&m.stats[S_SWEPT], swept);
-#ifdef SE_SCHED_TIMING
-  if (lane == 0 && !(scheduler && blockIdx.x == 0)) atomicMax(&m.stats[15], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
   for (uint32_t tid = blockIdx.x * SE_WG + threadIdx.x; tid < nnodes * 8u; tid += gridDim.x * SE_WG)
     se_update_node_corner<OFUSION>(m, depthmap, a, tid);
 }
@@ -1000,13 +978,14 @@ struct RayArgs {
   int has_deep;          // there are non-leaf levels beyond the staged ones (volumes > 512^3)
   int stack_depth;   // ray stack slots (= leaf level)
   // Beam start (r05; results do not depend on it, see se_beam_start): sample spacing along the tile's centre ray, edge of a coarse cell, its inverse, 1 / dim
-  int beam;
+  int beam;          // 0 off, 1 coarse stage, 2 coarse + fine stage
   float beam_dt, beam_cell, beam_inv_cell, inv_dim;
+  float beam_dt2, beam_cellf, beam_inv_cellf;     // second stage: the block grid itself (DevMap::fbits)
   // Scheduling (results do not depend on it).  tile_cost[] = cost of every wave tile (8x8 pixels) in the previous
   // raycast launch, trips + 5 * march batches of its slowest ray.  All waves of a 640x480 launch are resident from the
   // first microsecond, every SIMD works through the 4-5 tiles the dispatcher gives it, and the launch lasts as long as the
   // unluckiest SIMD: with workgroups in image order the cost sums per SIMD spread 3x (115..343 around a median of 179,
-  // tools/ray_diag.py) and the SIMD finish times 24..42 us follow them (correlation 0.85).  The dispatcher hands workgroup
+  // r02 per-wave records) and the SIMD finish times 24..42 us follow them (correlation 0.85).  The dispatcher hands workgroup
   // i to compute unit i mod n_cus (observed; a speed assumption only), so the integration sweep sorts the workgroups' tile
   // pairs by previous cost (ray_order) and workgroup i takes the pair at position (i / n_cus, i mod n_cus) of a snake deal:
   // every compute unit gets one pair of each cost stratum.  On top, the waves of the costliest tiles -- the silhouettes
@@ -1023,17 +1002,7 @@ struct RayArgs {
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
                        // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
-#ifdef SE_DIAG
-  int debug_phases;    // diagnostic build only: bit0 = skip march + gradient, bit1 = skip gradient, bit2 = skip the traversal (results are then wrong)
-  uint32_t* diag_pix;  // per pixel: iterator trips | march batches << 16 (STATS variants)
-  uint32_t* diag_wave; // per wave: 8 words, see k_raycast
-#endif
 };
-#ifdef SE_DIAG
-#define SE_DBG_PHASES(a) ((a).debug_phases)
-#else
-#define SE_DBG_PHASES(a) 0
-#endif
 
 struct BlkCache { int bx, by, bz; uint32_t e; };
 // voxel_traits<T>::initValue() / empty() as register values.  Reading them through the by-value
@@ -1369,7 +1338,7 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
   // only the rare events are branches: leaving a parent (stack read), entering a leaf parent (sibling
   // byte load) and the global occupancy word of volumes > 512^3.
   before_loop();
-  const int max_trips = ((SE_DBG_PHASES(a) & 4) || !live) ? 0 : 4096;
+  const int max_trips = live ? 4096 : 0;
   const bool has_deep = SHALLOW ? false : (a.has_deep != 0);
   int guard = 0;
   // The occupancy word of a trip depends only on (parent, pos, scale), which are final at the end of the previous
@@ -1516,7 +1485,7 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
 #define SE_SIB_OF(P) ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)] : (uint32_t)occ_bytes[(P)])
   uint32_t sib = s_occ8[1];   // the root's children: word 0 of the occupancy bits is always staged
   int guard = 0;
-  const int max_trips = ((SE_DBG_PHASES(a) & 4) || !live || redo) ? 0 : 4096;
+  const int max_trips = (!live || redo) ? 0 : 4096;
   for (; guard < max_trips && scale < 23; ++guard) {
     const f3 t_corner = f3_sub(f3_mul(pos, t_coef), t_bias);
     const float tc_max = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
@@ -2040,7 +2009,8 @@ __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, c
 // of p -- rmax = the largest distance between a ray's unit direction and the centre ray's (over the wave's 64 lanes, +5 %), eps the iterator's
 // clamp of near-zero direction components (ray_iterator.hpp:63-75: the traversed line differs from the true one by at most eps t) -- and the
 // sample counts as clear only if that bound is below 0.9 cell.  t_safe = the end of the clear run from the near plane; the rays enter the tree there
-// (se_first_leaf_lite).  Conservative by construction: centimetres of margin against rounding, a bit set concurrently by the next frame's scan
+// (se_first_leaf_lite).  CPU model of both stages against the reference iterator, ray by ray: tests/cpp/first_leaf_equiv.cpp (17.7 -> 13.5 -> 10.4 trips
+// per ray on the benchmark stream, 62 -> 24 -> 17 for OFusion on the stress stream).  Conservative by construction: centimetres of margin against rounding, a bit set concurrently by the next frame's scan
 // only shortens the run, NaN anywhere fails the bound -> no jump.
 __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a, f3 org, f3 dir, float tile_cx, float tile_cy) {
   const f3 dc = f3_normalized(m3_mul(a.view3, {tile_cx, tile_cy, 1.f}));
@@ -2059,8 +2029,26 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
   const bool clear = !occupied && ((ti + 0.5f * a.beam_dt) * rad + 0.5f * a.beam_dt <= 0.9f * a.beam_cell);
   const unsigned long long blocked = __ballot(!clear);
   const int j = blocked ? (int)__builtin_ctzll(blocked) : 64;
-  if (j < 1) return 0.f;
-  return (a.nearp + ((float)j - 0.5f) * a.beam_dt) * a.inv_dim;
+  float t_safe = j < 1 ? 0.f : a.nearp + ((float)j - 0.5f) * a.beam_dt;
+  if (a.beam >= 2) {
+    // second stage, from the end of the coarse run on: the same test against fbits, the block grid's own resolution dilated by one block -- the coarse
+    // stage stops 15-45 cm in front of the first block near the beam (one coarse cell of dilation, one of quantisation, half a sample), this one 1-2 blocks
+    const float t1 = fmaxf(t_safe, a.nearp);
+    const float tf = t1 + ((float)lane + 0.5f) * a.beam_dt2;
+    const f3 pf = f3_add(org, f3_scale_r(dc, tf));
+    const int F = m.leaf_level;
+    const int fx = se_cvt_flr(pf.x * a.beam_inv_cellf), fy = se_cvt_flr(pf.y * a.beam_inv_cellf), fz = se_cvt_flr(pf.z * a.beam_inv_cellf);
+    const bool inf = (uint32_t)(fx | fy | fz) < (1u << F);
+    const uint32_t fidx = inf ? (((uint32_t)fz << (2 * F)) | ((uint32_t)fy << F) | (uint32_t)fx) : 0u;
+    const uint32_t fw = m.fbits[fidx >> 5];
+    const bool clear2 = !(inf && ((fw >> (fidx & 31u)) & 1u)) && ((tf + 0.5f * a.beam_dt2) * rad + 0.5f * a.beam_dt2 <= 0.9f * a.beam_cellf);
+    const unsigned long long blocked2 = __ballot(!clear2);
+    const int j2 = blocked2 ? (int)__builtin_ctzll(blocked2) : 64;
+    if (j2 > 0) t_safe = t1 + (float)j2 * a.beam_dt2;
+  }
+  // (never beyond the far plane: the iterator descends into a node only while t_min <= far / dim, but returns the leaves of a node it is already in
+  // whatever their distance -- up to a node's width behind the far plane; a search started there would never descend and miss them)
+  return fminf(t_safe, a.farp) * a.inv_dim;
 }
 
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
@@ -2079,9 +2067,6 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
   if (a.gate && bid == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-#ifdef SE_DIAG
-  const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz, the same counter on every CU
-#endif
   // LDS staging of the occupancy words, split in two: the global loads are issued here, the LDS writes and the barrier
   // follow the ray set-up inside se_first_leaf (a per-level copy of only the used words was slower)
   constexpr int kStage = 2048 / SE_WG_RAY;      // occupancy levels <= 5 are 2048 words
@@ -2118,9 +2103,6 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     else if (prev >= a.prio_thr[0]) __builtin_amdgcn_s_setprio(1);
   }
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
-#ifdef SE_DIAG
-  unsigned d_trips = 0, d_batches = 0;
-#endif
   const bool in_image = px < a.W && py < a.row_end;
   const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
   const f3 org = {a.org[0], a.org[1], a.org[2]};
@@ -2144,26 +2126,17 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     if (STATS) tk2 = __builtin_amdgcn_s_memtime();
     float hx = 0.f, hy = 0.f, hz = 0.f, hw = 0.f;
     BlkCache c = {-1, -1, -1, 0u};
-    if (t_min > 0.f && !(SE_DBG_PHASES(a) & 1)) {
+    if (t_min > 0.f) {
       RayCounters rc = {0ull, 0ull, 0u};
       se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
       if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
       my_cost = (unsigned)SE_COST_BATCH * rc.n_batch;
-#ifdef SE_DIAG
-      if (STATS) d_batches = rc.n_batch;
-#endif
     }
     my_cost += (unsigned)span.trips;
-#ifdef SE_DIAG
-    if (STATS) { d_trips = (unsigned)span.trips; if (a.diag_pix) a.diag_pix[px + py * a.W] = d_trips | (d_batches << 16); }
-#endif
     if (STATS) tk3 = __builtin_amdgcn_s_memtime();
     float* v = vertex + 3 * (size_t)(px + py * a.W);
     float* n = normal + 3 * (size_t)(px + py * a.W);
-    if (SE_DBG_PHASES(a) & 1) hw = t_min;
-    if (hw > 0.f && (SE_DBG_PHASES(a) & 3)) {
-      v[0] = hx; v[1] = hy; v[2] = hw; n[0] = 0.f; n[1] = 0.f; n[2] = 0.f;
-    } else if (hw > 0.f) {   // (hit.w() > 0.0)
+    if (hw > 0.f) {   // (hit.w() > 0.0)
       if (STATS) { ++n_hit; ++n_grad; }
       v[0] = hx; v[1] = hy; v[2] = hz;
       const f3 g = DENSE ? se_grad_lean<O32>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c) : se_grad<DENSE>(m, fc, f3_scale(a.inv_voxel, {hx, hy, hz}), c);
@@ -2186,14 +2159,8 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     atomicMax(slot, my_cost);
     if (lane == 0 && tile_in_image) a.tile_cost[tile_slot] = (unsigned short)min(*slot >> a.cost_shift, 65535u);
   }
-#ifdef SE_DIAG
-  const bool quiet = a.diag_wave != nullptr;   // per-wave records only: the contended stats atomics would distort the clocks
-#else
-  const bool quiet = false;
-#endif
   if (STATS) {
     const unsigned long long tk4 = __builtin_amdgcn_s_memtime();
-    if (!quiet) {
     se_stat_add<true>(m, S_GETS, n_get);
     se_stat_add<true>(m, S_INTERPS, n_interp);
     se_stat_add<true>(m, S_GRADS, n_grad);
@@ -2209,22 +2176,6 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
       atomicMax(&m.stats[14], tk3 - tk2);
       atomicMax(&m.stats[15], tk4 - tk3);
     }
-    }
-#ifdef SE_DIAG
-    // per-wave record: start / end clock (low words), phase cycles, wave-level trip and batch counts, where it ran
-    if (a.diag_wave && tile_in_image) {
-      unsigned mt = d_trips, mb = d_batches;
-      for (int o = 32; o > 0; o >>= 1) { mt = max(mt, (unsigned)__shfl_xor((int)mt, o)); mb = max(mb, (unsigned)__shfl_xor((int)mb, o)); }
-      if (lane == 0) {
-        uint32_t hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        uint32_t* w = a.diag_wave + 8 * (size_t)tile;
-        w[0] = (uint32_t)rt0; w[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); w[2] = (uint32_t)(tk1 - tk0); w[3] = (uint32_t)(tk2 - tk1);
-        w[4] = (uint32_t)(tk3 - tk2); w[5] = (uint32_t)(tk4 - tk3); w[6] = mt | (mb << 16); w[7] = hwid ^ (xcc << 28);
-      }
-    }
-#endif
   }
 }
 

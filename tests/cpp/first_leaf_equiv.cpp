@@ -131,7 +131,8 @@ template <typename VT> static std::vector<uint32_t> coarse_bits(const Octree<VT>
   return bits;
 }
 // se_beam_start of se_kernels.h for the tile whose first pixel is (x0, y0): the 64 "lanes" are the tile's pixels
-template <typename VT> static float beam_start(const Octree<VT>& m, const std::vector<uint32_t>& cbits, int C, const M4& view, int x0, int y0, float nearP, float farP) {
+template <typename VT> static float beam_start(const Octree<VT>& m, const std::vector<uint32_t>& cbits, int C, const M4& view, int x0, int y0, float nearP, float farP,
+                                               const std::vector<uint32_t>* fbits = nullptr, int Fl = 0) {
   const V3f org = {view.m[0][3], view.m[1][3], view.m[2][3]};
   const V3f dc = normalized(mul3(top3(view), {(float)x0 + 3.5f, (float)y0 + 3.5f, 1.f}));
   float dev = 0.f;
@@ -156,7 +157,27 @@ template <typename VT> static float beam_start(const Octree<VT>& m, const std::v
     if (!clear) { j = l; break; }
   }
   if (j < 1) return 0.f;
-  return (nearP + ((float)j - 0.5f) * dt) * inv_dim;
+  float t_safe = nearP + ((float)j - 0.5f) * dt;
+  if (fbits) {
+    // stage 2: the same test on the fine grid (level Fl, dilated by one fine cell), 64 samples from t_safe on
+    const float cellf = m.dim_ / (float)(1 << Fl), inv_cellf = (float)(1 << Fl) / m.dim_;
+    const float dt2 = 0.4f * cellf;
+    int j2 = 64;
+    for (int l = 0; l < 64; ++l) {
+      const float ti = t_safe + ((float)l + 0.5f) * dt2;
+      const V3f p = org + dc * ti;
+      const int cx = (int)floorf(p.x * inv_cellf), cy = (int)floorf(p.y * inv_cellf), cz = (int)floorf(p.z * inv_cellf);
+      const bool in = (uint32_t)(cx | cy | cz) < (1u << Fl);
+      const uint32_t idx = in ? (((uint32_t)cz << (2 * Fl)) | ((uint32_t)cy << Fl) | (uint32_t)cx) : 0u;
+      const bool occupied = in && (((*fbits)[idx >> 5] >> (idx & 31u)) & 1u);
+      const bool clear = !occupied && ((ti + 0.5f * dt2) * rad + 0.5f * dt2 <= 0.9f * cellf);
+      if (!clear) { j2 = l; break; }
+    }
+    t_safe += (float)j2 * dt2;
+  }
+  // never beyond the far plane: the iterator descends into a node only while t_min <= far / dim, but returns leaves of a node it is already in
+  // whatever their distance -- a start behind the far plane would never descend and miss those
+  return fminf(t_safe, farP) * inv_dim;
 }
 
 template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad, int beam) {
@@ -168,9 +189,13 @@ template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm
   const int tiles_x = (p->W + 7) / 8, tiles_y = (p->H + 7) / 8;
   if (beam) {
     cbits = coarse_bits(oct, C);
+    const int Fl = oct.max_level_ - 3;
+    std::vector<uint32_t> fbits;
+    if (beam >= 2 && Fl > C) fbits = coarse_bits(oct, Fl);
     tile_start.resize((size_t)tiles_x * tiles_y);
     for (int ty = 0; ty < tiles_y; ++ty)
-      for (int tx = 0; tx < tiles_x; ++tx) tile_start[(size_t)ty * tiles_x + tx] = beam_start(oct, cbits, C, view, tx * 8, ty * 8, nearPlane, farPlane);
+      for (int tx = 0; tx < tiles_x; ++tx)
+        tile_start[(size_t)ty * tiles_x + tx] = beam_start(oct, cbits, C, view, tx * 8, ty * 8, nearPlane, farPlane, fbits.empty() ? nullptr : &fbits, Fl);
   }
   int64_t rays = 0, irregular = 0, flagged = 0, mismatch = 0, found = 0, trips_ref = 0, trips_lite = 0, model_bug = 0;
   int bad_x = -1, bad_y = -1;
@@ -207,4 +232,20 @@ extern "C" void fl_compare(void* pipe, const float* pose_cm, const float* k, int
   PipelineBase* b = (PipelineBase*)pipe;
   if (auto* s = dynamic_cast<Pipeline<SDFv>*>(b)) fl::compare(s, pose_cm, k, out, first_bad, beam);
   else if (auto* o = dynamic_cast<Pipeline<OFv>*>(b)) fl::compare(o, pose_cm, k, out, first_bad, beam);
+}
+
+// debug: one pixel
+extern "C" void fl_debug(void* pipe, const float* pose_cm, const float* k, int x, int y, int beam, double* out) {
+  auto* p = dynamic_cast<Pipeline<SDFv>*>((PipelineBase*)pipe);
+  const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
+  const Octree<SDFv>& oct = p->oct;
+  const int C = std::min(oct.max_level_ - 3, 5), Fl = oct.max_level_ - 3;
+  auto cb = fl::coarse_bits(oct, C), fb = fl::coarse_bits(oct, Fl);
+  const float ts = fl::beam_start(oct, cb, C, view, (x / 8) * 8, (y / 8) * 8, nearPlane, farPlane, beam >= 2 ? &fb : nullptr, Fl);
+  const V3f dir = normalized(mul3(top3(view), {(float)x, (float)y, 1.f}));
+  const V3f transl = {view.m[0][3], view.m[1][3], view.m[2][3]};
+  RayIterator<SDFv> ray(oct, transl, dir, nearPlane, farPlane);
+  const bool ref_found = ray.next() != nullptr;
+  const fl::Result a = fl::lite(oct, transl, dir, nearPlane, farPlane, 0.f), b = fl::lite(oct, transl, dir, nearPlane, farPlane, ts);
+  out[0] = ts * oct.dim_; out[1] = ray.t_min_ * oct.dim_; out[2] = ref_found; out[3] = a.t_min * oct.dim_; out[4] = a.found; out[5] = b.t_min * oct.dim_; out[6] = b.found; out[7] = b.flagged; out[8] = a.trips; out[9] = b.trips;
 }

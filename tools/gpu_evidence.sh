@@ -1,13 +1,13 @@
 #!/bin/bash
-# The evidence runs of round 4 (one gpurun call each):
-#   tools/gpu_r04_evidence.sh final [tag]   full rocprofv3 passes (kernel trace + FETCH / WRITE / SQ / cache / TLB / latency counters, separate runs) of the
+# The evidence runs of a round (one gpurun call each; r04: tags r04m, r04r, r04u, r04y -- r05: r05k, r05z):
+#   tools/gpu_evidence.sh final [tag]   full rocprofv3 passes (kernel trace + FETCH / WRITE / SQ / cache / TLB / latency counters, separate runs) of the
 #                                           four BASELINE workloads that fit one GPU, then configs 2..5 + the stress stream through bench.py   (r04m, r04r)
-#   tools/gpu_r04_evidence.sh last [tag]    smoke, every GPU test, the driver's two bench commands, the tracked loop's probe + kernel trace, configs + stress (r04u)
-#   tools/gpu_r04_evidence.sh close [tag]   the full rocprofv3 passes of the headline workload, every GPU test, the driver's two bench commands        (r04y)
+#   tools/gpu_evidence.sh last [tag]    smoke, every GPU test, the driver's two bench commands, the tracked loop's probe + kernel trace, configs + stress (r04u)
+#   tools/gpu_evidence.sh close [tag]   the full rocprofv3 passes of the headline workload, every GPU test, the driver's two bench commands        (r04y)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 MODE=${1:-close}
-T=${2:-r04}
+T=${2:-r05}
 configs_and_stress() {
   SE_CFG_SKIP_MU01=1 bash tools/gpu_configs.sh 2>&1 | tee gpurun_out/${T}_configs.log | cut -c1-320
   for t in sdf512 sdf512_icl sdf1024 sdf2048 ofusion512; do cp gpurun_out/cfg_$t.json gpurun_out/${T}_cfg_$t.json; done
