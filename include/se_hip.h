@@ -15,7 +15,8 @@
  *     frame", 0 = "gated off", like the reference's bool), < 0 = SE_HIP_E_* ; nothing throws,
  *     nothing calls exit(); se_hip_last_error() gives a message for the calling thread.
  *   - 4x4 matrices are 16 floats in COLUMN-MAJOR order, i.e. Eigen::Matrix4f::data().
- *   - k = (fx, fy, cx, cy) as Eigen::Vector4f k in the reference API.
+ *   - k = (fx, fy, cx, cy) as Eigen::Vector4f k in the reference API.  A pose or k holding a NaN or an infinity (or fx, fy = 0) is refused with
+ *     SE_HIP_E_INVALID by every stage call: the reference would fuse garbage; this library's parity argument is made for finite rays.
  *   - one handle <-> one caller thread at a time (the reference is not re-entrant either).
  *   - all work is enqueued on one HIP stream per handle; calls that return data to the host
  *     synchronise that stream, the others are asynchronous -- with one exception (the "host gate", dense unsharded
@@ -83,7 +84,7 @@ int se_hip_clear_overflow(se_hip_pipeline* p);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the handle's own. */
 int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
 /* The stream the allocation scan (se_hip_alloc_scan) is launched on when it overlaps the previous
- * frame's raycast (see DESIGN.md 4.3).  The multi-GPU driver passes the stream its
+ * frame's raycast (see DESIGN.md 4.4).  The multi-GPU driver passes the stream its
  * all-gather of the key lists is ordered on, so that scan + exchange of frame f+1 hide behind the
  * raycast of frame f.  NULL = a stream owned by the handle (the default). */
 int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);

@@ -47,7 +47,8 @@ struct DevMap {
                                   // before it touches a brick or the index: 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 -- L2-resident)
   uint32_t* cbits;                // beam start of the raycast: one bit per cell of the COARSE grid (level clevel, linear x + (y << clevel) + (z << 2 clevel)),
                                   // set for every cell within one cell (27-neighbourhood) of an allocated block: 4 KB at level 5.  A clear bit = no block anywhere
-                                  // within one coarse cell of any point of this cell.  Only ever set (never cleared: blocks are never freed).
+                                  // within one coarse cell of any point of this cell.  Only ever set (never cleared: blocks are never freed).  The second
+                                  // half of the allocation holds the same grid undilated ("a block exists in this cell": se_mark_coarse).
   int clevel;
   uint32_t* fbits;                // the same at the block grid's own resolution (level leaf_level): set for every cell within one BLOCK of an allocated block;
                                   // 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 (second stage of the beam start); null if leaf_level <= clevel

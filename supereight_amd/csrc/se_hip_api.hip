@@ -429,6 +429,15 @@ void select_image_target(se_hip_pipeline* p, uint32_t frame) {
 // scope of an entry point that may run with a deferred raycast outstanding (check() then leaves it alone)
 struct InFrame { se_hip_pipeline* p; bool was; explicit InFrame(se_hip_pipeline* q) : p(q), was(q->in_frame) { q->in_frame = true; } ~InFrame() { p->in_frame = was; } };
 
+// A pose or intrinsics with a NaN or an infinity in it is refused (SE_HIP_E_INVALID) instead of integrated: the reference would fuse garbage, and the
+// kernels' cheap conversions (hardware float -> int in the march, the sweep's pixel index) are only argued equal to the reference's for finite rays.
+bool finite_pose(const float* pose_cm, const float* k) {
+  bool ok = true;
+  for (int i = 0; i < 16; ++i) ok = ok && std::isfinite(pose_cm[i]);
+  for (int i = 0; i < 4; ++i) ok = ok && std::isfinite(k[i]);
+  return ok && k[0] != 0.f && k[1] != 0.f;
+}
+
 bool stage_runs_integration(uint32_t frame, uint32_t rate) { return ((frame % rate) == 0) || (frame <= 3); }
 
 // Octree::init (se_core/include/se/octree.hpp:425-437) on the device: empty index, root node, every brick and node value
@@ -438,7 +447,7 @@ void reset_map_state(se_hip_pipeline* p) {
   hipMemsetAsync(m.tab, 0, p->tab_entries * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.occ, 0, p->occ_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.lbits, 0, p->lbits_words * sizeof(uint32_t), p->stream);
-  hipMemsetAsync(m.cbits, 0, p->cbits_words * sizeof(uint32_t), p->stream);
+  hipMemsetAsync(m.cbits, 0, 2 * p->cbits_words * sizeof(uint32_t), p->stream);   // (dilated bits + the cells' own "has a block" bits)
   if (m.fbits) hipMemsetAsync(m.fbits, 0, p->fbits_words * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bpos, 0, p->cap_blocks * sizeof(uint32_t), p->stream);
   hipMemsetAsync(m.bactive, 0, p->slots, p->stream);
@@ -568,7 +577,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(m.lbits, p->lbits_words * sizeof(uint32_t));
   m.clevel = std::min(p->leaf_level, 5);      // coarse cells of dim / 32 (15 cm at 4.8 m): see se_beam_start
   p->cbits_words = std::max<size_t>(1, ((size_t)1 << (3 * m.clevel)) / 32);
-  ALLOC(m.cbits, p->cbits_words * sizeof(uint32_t));
+  ALLOC(m.cbits, 2 * p->cbits_words * sizeof(uint32_t));   // [dilated bits][undilated bits of the same grid: se_mark_coarse]
   m.fbits = nullptr;
   if (p->leaf_level > m.clevel) { p->fbits_words = cells / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
@@ -830,6 +839,7 @@ int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& s
 int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
   if (int r = check(p)) return r;
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!finite_pose(pose_cm, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   if (!stage_runs_integration(frame, rate)) return 0;  // DenseSLAMSystem.cpp:209
   const DevMap& m = p->map;
   const M4 pose = from_colmajor(pose_cm);
@@ -1038,6 +1048,7 @@ int se_hip_brick_exchange(se_hip_pipeline* p, void* recv_device) {
 int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
   if (int r = check(p)) return r;
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!finite_pose(pose_cm, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   if (!stage_runs_integration(frame, rate)) return 0;
   if (int r = check_overflow(p)) return r;
   if (int r = join_scan(p, true)) return r;
@@ -1190,6 +1201,7 @@ int se_hip_integrate(se_hip_pipeline* p, const float pose[16], const float k[4],
   InFrame guard(p);
   if (int r = check(p)) return r;
   if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!finite_pose(pose, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   // a deferred raycast must run before this frame's sweep: together with this frame's scan if there is one, else on its own, now
   if (p->has_pending && !(frame_can_fuse(p) && stage_runs_integration(frame, rate))) { if (int r = flush_pending_raycast(p)) return r; }
   int r = se_hip_alloc_scan(p, pose, k, rate, mu, frame);
@@ -1204,6 +1216,7 @@ int se_hip_raycast_deferred(se_hip_pipeline* p, const float pose[16], const floa
   InFrame guard(p);
   if (int r = check(p)) return r;
   if (!pose || !k) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!finite_pose(pose, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   if (p->has_pending) { if (int r = flush_pending_raycast(p)) return r; }   // two raycasts without an integration between them
   if (!(frame > 2)) return 0;      // DenseSLAMSystem.cpp:195
   if (!frame_can_fuse(p)) return se_hip_raycast(p, pose, k, mu, frame);
@@ -1220,6 +1233,7 @@ int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float po
   InFrame guard(p);
   if (int r = check(p)) return r;
   if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!finite_pose(pose, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   if (device_depth_m) p->depth = device_depth_m;
   int ran = 0;
   int r = se_hip_integrate(p, pose, k, rate, mu, frame);
@@ -1235,6 +1249,7 @@ int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float po
 int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4], float mu, uint32_t frame) {
   if (int r = check(p)) return r;
   if (!pose_cm || !k) return fail(SE_HIP_E_INVALID, "bad argument");
+  if (!finite_pose(pose_cm, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   if (!(frame > 2)) return 0;  // DenseSLAMSystem.cpp:195
   if (int r = check_overflow(p)) return r;
   if (int r = join_scan(p)) return r;

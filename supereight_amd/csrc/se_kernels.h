@@ -52,11 +52,13 @@ __device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, 
 // Inserts the octant (x,y,z)@level (block if level == leaf_level, else an internal node with no
 // children yet) if absent.  Returns true if this thread created it.
 // A new block marks its cell and the 26 around it in a dilated bitmap of level C (cbits: the coarse grid, fbits: the block grid itself; se_device.h).
-// (cx, cy, cz) = the block's cell at that level.  Read first: almost every bit is set already.
-// Per (y, z) neighbour the three x-neighbours are adjacent bits: one atomic OR, two where they straddle a word.  No read-before-write and nothing
-// that returns a value: the thread that inserts a block must not wait -- a first version that looked at each word first (27 dependent round trips in a
-// rolled loop) made the one inserting lane of a wave the last thing alive in the launch and doubled the allocation scan's duration.  A rolled loop
-// because the call sits in the rare insertion branch of the scans' unrolled flush code (eight copies).
+// Per (y, z) neighbour the three x-neighbours are adjacent bits of one word, or of two where they straddle a boundary: atomic ORs whose result nobody
+// reads -- the inserting lane never waits for them.  A rolled loop: the call sits in the rare insertion branch of the scans' unrolled flush code.
+// How NOT to do it, both measured: (1) looking at each word before writing it, word by word, is 27 dependent round trips on one lane and doubled the
+// scan's duration (profiles/r05l, r05n; three batched reads per bitmap still cost the stress stream 11 % of its frame rate, profiles/r05s); (2) ORs
+// without any test are thousands of atomics per frame onto the few hot words of the COARSE bitmap at 2048^3 -- one word takes ~90 atomics per
+// microsecond -- and the scan beside the raycast went from 272 to 442 us (profiles/r05r_configs.log).  Hence se_mark_coarse below: the coarse dilation
+// is done once per coarse cell (one read of the cell's own "has a block" bit decides), the fine one per block.
 __device__ __forceinline__ void se_mark_dilated(uint32_t* bits, int C, int cx, int cy, int cz) {
   const int n = 1 << C;
   const int lo = max(cx - 1, 0), hi = min(cx + 1, n - 1);
@@ -64,16 +66,23 @@ __device__ __forceinline__ void se_mark_dilated(uint32_t* bits, int C, int cx, i
   for (int k = 0; k < 9; ++k) {
     const int uy = cy + (k % 3) - 1, uz = cz + (k / 3) - 1;
     if ((unsigned)uy >= (unsigned)n || (unsigned)uz >= (unsigned)n) continue;
-    const uint32_t base = ((uint32_t)uz << (2 * C)) | ((uint32_t)uy << C);
-    const uint32_t i0 = base + (uint32_t)lo, i1 = base + (uint32_t)hi;
+    const uint32_t i0 = (((uint32_t)uz << (2 * C)) | ((uint32_t)uy << C)) + (uint32_t)lo;
     const unsigned long long run = ((1ull << (hi - lo + 1)) - 1ull) << (i0 & 31u);     // bits lo .. hi relative to word i0 >> 5
     atomicOr(bits + (i0 >> 5), (uint32_t)run);
-    if ((i1 >> 5) != (i0 >> 5)) atomicOr(bits + (i1 >> 5), (uint32_t)(run >> 32));
+    if ((uint32_t)(run >> 32)) atomicOr(bits + (i0 >> 5) + 1, (uint32_t)(run >> 32));
   }
 }
 __device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, int bz) {
-  const int sh = m.leaf_level - m.clevel;
-  se_mark_dilated(m.cbits, m.clevel, bx >> sh, by >> sh, bz >> sh);
+  const int C = m.clevel, sh = m.leaf_level - C;
+  const int cx = bx >> sh, cy = by >> sh, cz = bz >> sh;
+  // cown = the undilated coarse occupancy ("a block exists IN this coarse cell"), the second half of the cbits allocation: whoever finds the bit set
+  // knows that an earlier block of the same cell has dilated it already (two racing first blocks both do it: idempotent)
+  uint32_t* cown = m.cbits + ((size_t)1 << (3 * C)) / 32 + (C < 2 ? 1 : 0);
+  const uint32_t idx = ((uint32_t)cz << (2 * C)) | ((uint32_t)cy << C) | (uint32_t)cx, bit = 1u << (idx & 31u);
+  if (!(*(volatile uint32_t*)(cown + (idx >> 5)) & bit)) {
+    atomicOr(cown + (idx >> 5), bit);
+    se_mark_dilated(m.cbits, C, cx, cy, cz);
+  }
   if (m.fbits) se_mark_dilated(m.fbits, m.leaf_level, bx, by, bz);
 }
 
@@ -1546,7 +1555,7 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
 struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 
 // ---- lean dense-grid march (r04) ---------------------------------------------------------------------------------
-// The raycast is bound by VALU issue slots (DESIGN 4.2), and by r03's counters two thirds of the march's instructions
+// The raycast is bound by VALU issue slots (DESIGN 4.3), and by r03's counters two thirds of the march's instructions
 // were address arithmetic and range bookkeeping, not the reference's float operations.  For the dense grid:
 //  * float -> int by the hardware conversion (one instruction) instead of the compare-and-select restatement of x86's
 //    cvttss2si: the two agree for |f| < 2^31 and differ only for NaN (0 instead of INT_MIN) -- rays whose direction or
@@ -1740,7 +1749,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
     if constexpr (SE_MARCH_PROBE && !O32) {
      if (unobs) {
       probed = true;
-      // Volumes > 512^3: the march is latency-bound on cold brick lines (DESIGN 4.2), and 43 % of its samples lie in blocks that were
+      // Volumes > 512^3: the march is latency-bound on cold brick lines (DESIGN 4.3), and 43 % of its samples lie in blocks that were
       // never allocated -- whose bricks the dense grid backs with real memory nobody else touches.  While the march walks through
       // unobserved space (the last value had weight 0) it asks the leaf bitmap first (L2-resident) and reads a brick only where a
       // block exists; an absent block reads as initValue(), which is what its brick holds.
@@ -2186,7 +2195,7 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
 }
 // r04: raycast of frame f and allocation scan of frame f+1 in ONE launch on ONE queue.  The two always ran side by side (the scan on a second
 // queue behind a host gate), and the price of the second queue was the wait in front of the next sweep: 5.3 us of a 67 us frame for an event that
-// has long fired when the queue reaches it (DESIGN 4.3).  Here the first `ray_wgs` workgroups are the raycast's, the rest the scan's: they share the
+// has long fired when the queue reaches it (DESIGN 4.4).  Here the first `ray_wgs` workgroups are the raycast's, the rest the scan's: they share the
 // chip exactly as before -- the raycast's workgroups are dispatched first, the scan's fill in as those retire -- and sweep(f) -> [raycast(f), scan(f+1)]
 // -> sweep(f+1) are consecutive launches of one queue with nothing between them.  The scan defers its occupancy bits (the raycast reads occ[]), the
 // sweep behind publishes them, as in the two-queue schedule.  Needs both frames' inputs at launch time: se_hip_frame defers a frame's raycast to the

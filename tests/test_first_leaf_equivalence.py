@@ -1,4 +1,4 @@
-"""CPU test of the claim behind k_raycast's stack-free first-leaf search (se_first_leaf_lite, DESIGN 4.2): for every ray that is
+"""CPU test of the claim behind k_raycast's stack-free first-leaf search (se_first_leaf_lite, DESIGN 4.3): for every ray that is
 regular at set-up and never descends from a cell it has, by t_corner, already left, the reference iterator's stack and `h`
 carry no information -- a model without them (tests/cpp/first_leaf_equiv.cpp) returns the bit-identical t_min and the same
 leaf-found decision as the oracle's restatement of se::ray_iterator (se_core/include/se/ray_iterator.hpp:53-226).  The

@@ -72,6 +72,17 @@ def test_gating_and_empty_input():
     assert p.counts() == (0, 1)                       # only the root node
     v, n = p.vertex_normal()
     assert (v == 0).all() and (n[..., 0] == -2).all() and (n[..., 1:] == 0).all()
+    # a pose or intrinsics with a NaN / infinity is refused by every stage call (the reference would fuse garbage): nothing is enqueued
+    from supereight_amd.pipeline import SeHipError
+    bad = pose(0, 1.2).copy(); bad[1, 3] = np.nan
+    p.setPose(bad)
+    for call in (lambda: p.integration(k, 1, 0.1, 7), lambda: p.raycasting(k, 0.1, 7), lambda: p.raycasting_deferred(k, 0.1, 7)):
+        with pytest.raises(SeHipError, match="non-finite"):
+            call()
+    p.setPose(pose(0, 1.2))
+    with pytest.raises(SeHipError, match="non-finite"):
+        p.integration(np.asarray([np.inf, 60.0, 32.0, 24.0], np.float32), 1, 0.1, 7)
+    assert p.counts() == (0, 1) and p.integration(k, 1, 0.1, 7) is True
     p.close()
 
 

@@ -15,14 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CFG = {"sdf512": (640, 480, 512, "sdf", 0.1, 60), "sdf1024": (640, 480, 1024, "sdf", 0.1, 50), "of512": (640, 480, 512, "ofusion", 0.008, 40),
        "sdf2048": (1280, 960, 2048, "sdf", 0.1, 24), "stress512": (640, 480, 512, "sdf", 0.1, 60), "stress1024": (640, 480, 1024, "sdf", 0.1, 50),
-       "pooled512": (640, 480, 512, "sdf", 0.1, 60), "pooled1024": (640, 480, 1024, "sdf", 0.1, 50), "pooled2048": (1280, 960, 2048, "sdf", 0.1, 24)}
+       "pooled512": (640, 480, 512, "sdf", 0.1, 60), "pooled1024": (640, 480, 1024, "sdf", 0.1, 50), "pooled2048": (1280, 960, 2048, "sdf", 0.1, 24),
+       "pooledstress512": (640, 480, 512, "sdf", 0.1, 60), "pooledstress1024": (640, 480, 1024, "sdf", 0.1, 50), "pooledof512": (640, 480, 512, "ofusion", 0.008, 40)}
 
 
 def frames_of(cfg, n):
     import numpy as np
     from supereight_amd.synthetic import make_stream
     W, H, N, field, mu, _ = CFG[cfg]
-    kind = "stress" if cfg.startswith("stress") else "room"
+    kind = "stress" if "stress" in cfg else "room"
     path = f"/tmp/lib_ab_{kind}_{W}x{H}_{n}.npz"
     if os.path.exists(path):
         z = np.load(path)
