@@ -109,7 +109,9 @@ __device__ __forceinline__ int cvt_i32(float f) {
   if (!(f > -2147483904.f && f < 2147483648.f)) return (int)0x80000000;
   return (int)f;
 }
-// float -> int32 by the hardware conversion (truncating, saturating, NaN -> 0): equals cvt_i32 for |f| < 2^31 and non-NaN f; one instruction
+// float -> int32 by the hardware conversion (truncating, saturating, NaN -> 0): equals cvt_i32 for |f| < 2^31 and non-NaN f; one instruction.
+// Used where the operand cannot be NaN: the stage calls refuse a pose / intrinsics with a NaN or an infinity (finite_pose, se_hip_api.hip), and with
+// finite origin and direction every march position org + dir * t (t finite: tnear < tfar <= far) is finite.
 __device__ __forceinline__ int se_cvt_hw(float f) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)

@@ -1733,6 +1733,9 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
   if (!(f_t > 0)) return;
   float S = a.largestep;
   bool done = false;
+  // (r05, measured and dropped: 4 samples per round trip instead of 2 from the 3rd / 6th batch of a ray on, outside the truncation band -- aimed at the
+  // silhouette rays whose 12-23 round trips end the launch: fused launch 43.2 / 41.8 instead of 35.8 us at 512^3, 75 / 73 instead of 71 us at 1024^3,
+  // profiles/r05w_deep_ab.log.  Every earlier attempt to trade instructions for round trips in this loop lost too: profiles/DESIGN_r01-r04.md 4.4)
   bool band = f_t < 1.f;   // the last value seen was inside the truncation band: the next sample probably wants its interpolated value
   bool unobs = false;      // the last consumed sample had weight 0 (unobserved space)
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
@@ -2095,6 +2098,9 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     const int rnd = bid / a.n_cus, cu = bid - rnd * a.n_cus;
     const int pos = rnd * a.n_cus + ((rnd & 1) ? a.n_cus - 1 - cu : cu);
     const int pair = pos < n_pairs ? (int)a.ray_order[pos] : n_pairs;   // (positions of the last, partial round beyond the list: no pair)
+    // (r05, measured and dropped: XCD x = workgroup index mod 8 taking the x-th contiguous band of tile pairs, so that a brick is cached by one L2 instead
+    // of up to eight -- without the cost-sorted deal the fused launch takes 41.0 instead of 36.2 us at 512^3, OFusion 100 instead of 88 us: the launch
+    // ends with its slowest compute unit, balance beats locality.  profiles/r05v_xcd_ab.log)
     tile = 2 * pair + (threadIdx.x >> 6);
   }
   int tx = tile % tiles_x, ty = tile / tiles_x;
