@@ -23,7 +23,7 @@ s = StressStream(W, H, 4.8)
 depth = torch.from_numpy(np.stack([s.depth(f) for f in range(PATH)])).cuda()
 poses = [to_colmajor(s.pose(f)) for f in range(PATH)]
 k = np.ascontiguousarray(s.k, np.float32)
-p = DenseSLAMPipeline((W, H), N, 4.8, field_type=SDF)
+p = DenseSLAMPipeline((W, H), N, 4.8, field_type=SDF, streaming=os.environ.get("SE_SOAK_EAGER") is None)   # the one-queue schedule unless SE_SOAK_EAGER is set
 out = {"workload": f"stress stream {W}x{H} -> {N}^3, {frames} frames (path of {PATH} repeated)", "windows": []}
 t0 = time.perf_counter()
 for f in range(frames):
