@@ -168,3 +168,58 @@ def test_weight_saturated_blocks_stay_bit_exact(max_blocks):
     r = compare_raycast(recs[-1], dim / N)
     assert r["hits_gpu"] > 1000 and r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, r
     cpu.close(); gpu.close()
+
+
+def _look(position, yaw_deg=0.0, pitch_deg=0.0, roll_deg=0.0):
+    """Camera->world pose: yaw about y, then pitch about x, then roll about z, at `position` (metres)."""
+    y, p, r = np.deg2rad([yaw_deg, pitch_deg, roll_deg])
+    Ry = np.array([[np.cos(y), 0, np.sin(y)], [0, 1, 0], [-np.sin(y), 0, np.cos(y)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(p), -np.sin(p)], [0, np.sin(p), np.cos(p)]])
+    Rz = np.array([[np.cos(r), -np.sin(r), 0], [np.sin(r), np.cos(r), 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Ry @ Rx @ Rz
+    T[:3, 3] = position
+    return T.astype(np.float32)
+
+
+@pytest.mark.parametrize("field,W,H,N,dim,mu,frames", [(SDF, 320, 240, 512, 4.8, 0.1, 8), (SDF, 160, 120, 1024, 4.8, 0.1, 5), (OFUSION, 160, 120, 256, 2.4, 0.02, 8)],
+                         ids=["sdf512", "sdf1024", "ofusion256"])
+def test_raycast_from_unusual_viewpoints(field, W, H, N, dim, mu, frames):
+    """The stream's own camera sits inside the room and looks along +z.  The raycast's per-tile start distance (se_beam_start) and its
+    first-leaf search have corner cases that camera never reaches: rays that enter the volume from outside, rays that leave it at
+    once, origins inside allocated blocks, a far plane that ends the ray before the first allocated block, views along the volume's
+    diagonal and against the integration direction.  Same map on both sides, then raycastKernel (kfusion/rendering_impl.hpp:40-123)
+    from each of these poses: bit for bit."""
+    cpu, gpu, _ = run_both(field, W, H, N, dim, mu, frames)
+    from supereight_amd.synthetic import intrinsics
+    k = intrinsics(W)
+    c = np.array([0.5, 0.5, 0.5]) * dim
+    views = {
+        "behind_the_volume": _look(c + [0, 0, -0.8 * dim]),                       # enters through z = 0 after 0.3 dim of nothing
+        "beside_the_volume": _look(c + [-0.7 * dim, 0, 0], yaw_deg=90),           # enters through x = 0
+        "above_looking_down": _look(c + [0, -0.75 * dim, 0], pitch_deg=-90),      # enters through y = 0 (rows run along world z)
+        "far_away": _look(c + [0, 0, -6.0 * dim]),                                # far plane (4 m) ends every ray before the volume
+        "turned_around": _look(np.array([0.34, 0.5, 0.24]) * dim, yaw_deg=180),   # back wall at 0.19 dim, against the integration direction
+        "diagonal_from_corner": _look(np.array([0.02, 0.02, 0.02]) * dim, yaw_deg=45, pitch_deg=-35),
+        "rolled_and_pitched": _look(np.array([0.4, 0.45, 0.3]) * dim, yaw_deg=-25, pitch_deg=20, roll_deg=30),
+        "nose_on_the_wall": _look(np.array([0.5, 0.5, 0.93]) * dim),              # origin inside the wall's band, surface 0.02 dim ahead
+        "inside_the_sphere": _look(np.array([0.5, 0.5, 0.62]) * dim),
+        "grazing_the_floor": _look(np.array([0.3, 0.94, 0.2]) * dim, yaw_deg=10, pitch_deg=-2),
+        "looking_out": _look(np.array([0.5, 0.5, 0.99]) * dim),                   # beyond the back wall, every ray leaves the volume at once
+    }
+    total_hits = 0
+    for i, (name, view) in enumerate(views.items()):
+        frame = 100 + i
+        gpu.setPose(view)
+        assert gpu.raycasting(k, mu, frame)
+        ran, v_c, n_c = cpu.raycast(view, k, mu, frame)
+        assert ran
+        v_g, n_g = gpu.vertex_normal()
+        r = compare_raycast({"v_c": v_c, "n_c": n_c, "v_g": v_g, "n_g": n_g}, dim / N)
+        print(name, json.dumps(r))
+        assert r["hitmask_mismatch"] == 0 and r["vertex_bit_mismatch_px"] == 0 and r["normal_bit_mismatch_px"] == 0, (name, r)
+        if name in ("far_away", "looking_out"):
+            assert r["hits_gpu"] == 0, (name, r)
+        total_hits += r["hits_gpu"]
+    assert total_hits > 5000      # the sweep looked at surfaces, not only at nothing
+    cpu.close(); gpu.close()
