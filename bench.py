@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=4, help="repetitions of the CPU baseline sample (the fastest is reported, all are listed)")
     ap.add_argument("--sustain", type=int, default=200, help="N = 1: after the K contract steps keep going until this many frames have been timed in total (0 = off)")
     ap.add_argument("--no-streaming", action="store_true", help="N = 1: the eager two-queue schedule instead of the one-queue streaming schedule (se_hip_set_streaming)")
+    ap.add_argument("--sharded-streaming", action="store_true",
+                    help="N > 1: the one-queue schedule for the row-sharded replicas too (all-gather and commit behind the fused launch on the main stream); "
+                         "default is the two-queue plan, whose all-gather hides behind the raycast (DESIGN.md section 7)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed GPU warm-up on a scratch map before the warm-up frames (see prewarm())")
     ap.add_argument("--shard-sweep", action="store_true", help="N > 1: owner-computes integration + brick all-gather instead of the replicated sweep (SURVEY 8e option 4; DESIGN.md section 7: measured slower, off by default)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the value_closed_loop leg (profiling runs: nothing behind the timed loop)")
@@ -447,7 +450,8 @@ def main():
 
     # the pipeline is created BEFORE the pre-warm and the scratch map is freed AFTER the timed regions: allocating or
     # freeing gigabytes idles the GPU for tens of milliseconds, long enough for the clocks to drop again
-    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank, shard_sweep=args.shard_sweep, streaming=not args.no_streaming)
+    sp = ShardedPipeline((W, H), N, dim, field, rank, world, local_rank, shard_sweep=args.shard_sweep,
+                         streaming=(not args.no_streaming) and (world == 1 or args.sharded_streaming))
     prewarm_frames, scratch = prewarm(args, field, depth_ptrs, poses, k, local_rank) if not args.no_prewarm else (0, None)
 
     def barrier():
@@ -506,7 +510,7 @@ def main():
         sustained = {"frames": K + extra, "fps": (K + extra) / (elapsed + (t3 - t2)), "fps_second_region": extra / (t3 - t2),
                      "launches_in_timed_regions": {kk: launched[kk] + launched2[kk] for kk in ("alloc_scan", "integrate", "raycast", "fused")},
                      "note": f"the K = {K} contract steps plus {extra} more frames of the same stream, two timed regions added up"}
-    fused_schedule = world == 1 and sp.p.frame_is_fused()
+    fused_schedule = sp.p.frame_is_fused()
     timings = sp.p.timings(reset=True) if not args.no_events else None
     sp.p.enable_timing(False)
     nblocks, nnodes = sp.p.counts()
@@ -527,7 +531,8 @@ def main():
             "config": {"workload": f"{stream_name} {W}x{H} -> {N}^3 / {dim} m "
                                    f"{'TSDF (SDF)' if field == SDF else 'occupancy (OFusion)'}, mu={mu}, integration_rate=1, "
                                    f"GT poses, frames {warm}..{warm + K - 1} timed",
-                       "schedule": ("one queue: raycast(f) + scan(f+1) in one launch, sweep(f+1) behind it (se_hip_set_streaming: se_hip_frame holds a frame's raycast back until the next call)" if fused_schedule
+                       "schedule": ("one queue: raycast(f) + scan(f+1) in one launch, sweep(f+1) behind it (se_hip_set_streaming: se_hip_frame holds a frame's raycast back until the next call)" if fused_schedule and world == 1
+                                    else "one queue: raycast(f) + scan(f+1) in one launch over the rank's rows, all-gather of the key lists + commit + sweep(f+1) behind it (--sharded-streaming)" if fused_schedule
                                     else "two queues: scan(f+1) on a side stream beside raycast(f), event wait in front of sweep(f+1)"),
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists" + (", sweep sharded by block owner + RCCL all-gather of the updated bricks" if sp.shard_sweep else ""),
                        "blocks_allocated": nblocks, "nodes_allocated": nnodes,

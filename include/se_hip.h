@@ -99,9 +99,9 @@ int se_hip_scan_overlaps(se_hip_pipeline* p);
  * The reference's loop is integration(f); raycasting(f); integration(f+1); ... (se_apps/src/benchmark.cpp:148-167).  A caller that streams frames
  * without looking at each frame's vertex_ / normal_ can have raycasting(f) and the allocation scan of integration(f+1) run as ONE launch on the
  * handle's stream: with se_hip_set_streaming(p, 1), se_hip_frame and se_hip_raycast_deferred do not enqueue the raycast of a frame but hold it back
- * until the next se_hip_integrate / se_hip_frame, which launches it together with that frame's scan.  ANY other entry point of this header
- * (se_hip_sync, the image getters, se_hip_raycast, se_hip_track, the render calls, ...; not: the depth uploads, se_hip_filter_depth,
- * se_hip_enable_timing, se_hip_get_launch_counts) launches an outstanding raycast first, so whatever is read THROUGH the API is what the eager
+ * until the next se_hip_integrate / se_hip_frame / se_hip_alloc_scan, which launches it together with that frame's scan.  ANY other entry point of
+ * this header (se_hip_sync, the image getters, se_hip_raycast, se_hip_track, the render calls, ...; not: the depth uploads, se_hip_filter_depth,
+ * se_hip_set_new_keys_buffer, se_hip_enable_timing, se_hip_get_launch_counts) launches an outstanding raycast first, so whatever is read THROUGH the API is what the eager
  * schedule gives.  Reading past the API is what the mode cannot make safe: a caller kernel ordered on the handle's stream behind se_hip_frame(f)
  * would find frame f-1's images.  Therefore
  *   - the mode is opt-in (off: se_hip_frame == se_hip_set_depth_device + se_hip_integrate + se_hip_raycast, all enqueued when it returns);
@@ -109,8 +109,11 @@ int se_hip_scan_overlaps(se_hip_pipeline* p);
  *     never coexist;
  *   - with an image ring (below) the contract is explicit: slot (f % slots) holds frame f's images once the NEXT se_hip_frame / se_hip_integrate
  *     call (or any flushing call) has returned and the handle's stream has reached that point.
- * Plain single-device handles whose raycast fits the chip in one round of workgroups (640x480: 2 400 of 2 560) fuse; others (row-sharded, exchange
- * set, caller key buffer, statistics on, larger images) keep the eager two-queue schedule whatever the flag says.
+ * Handles whose raycast fits the chip in one round of workgroups (640x480: 2 400 of 2 560) fuse; others (statistics on, sharded sweep, larger
+ * images) keep the eager two-queue schedule whatever the flag says.  Row-sharded replicas and handles with a caller key buffer or an exchange fuse
+ * too: the scan half of the launch writes the caller's list on the MAIN stream, and se_hip_alloc_exchange / se_hip_alloc_commit follow it there
+ * (se_hip_scan_overlaps still answers for the scans that do not ride in a raycast's launch: give such a handle the main stream as its scan
+ * stream, se_hip_set_scan_stream, so that both kinds are ordered with the caller's collective -- supereight_amd/multi_gpu.py does).
  * se_hip_set_streaming returns 1 if the handle will fuse, 0 if not (or off); se_hip_frame_is_fused reports the same without changing anything. */
 int se_hip_set_streaming(se_hip_pipeline* p, int32_t on);
 int se_hip_frame_is_fused(se_hip_pipeline* p);

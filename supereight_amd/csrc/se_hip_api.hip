@@ -427,7 +427,7 @@ void select_image_target(se_hip_pipeline* p, uint32_t frame) {
   }
 }
 // scope of an entry point that may run with a deferred raycast outstanding (check() then leaves it alone)
-struct InFrame { se_hip_pipeline* p; bool was; explicit InFrame(se_hip_pipeline* q) : p(q), was(q->in_frame) { q->in_frame = true; } ~InFrame() { p->in_frame = was; } };
+struct InFrame { se_hip_pipeline* p; bool was; explicit InFrame(se_hip_pipeline* q, bool on = true) : p(q), was(q->in_frame) { q->in_frame = on; } ~InFrame() { p->in_frame = was; } };
 
 // A pose or intrinsics with a NaN or an infinity in it is refused (SE_HIP_E_INVALID) instead of integrated: the reference would fuse garbage, and the
 // kernels' cheap conversions (hardware float -> int in the march, the sweep's pixel index) are only argued equal to the reference's for finite rays.
@@ -802,7 +802,7 @@ int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& s
   p->has_pending = false;
   if (int r = check_overflow(p)) return r;
   std::memcpy(p->raycast_pose, p->pend_pose, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
-  p->images_complete = true;
+  p->images_complete = !p->sharded;
   select_image_target(p, p->pend_frame);
   p->n_launch[SE_HIP_K_ALLOC_SCAN]++; p->n_launch[SE_HIP_K_COUNT]++;   // (the raycast half is counted by the timer scope below)
   RayLaunchArgs L = make_ray_args(p, p->pend_pose, p->pend_k, p->pend_mu);
@@ -836,7 +836,13 @@ int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& s
 }
 
 // ---------------------------------------------------------------------------------- integrate
+static bool frame_can_fuse(se_hip_pipeline* p);
 int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k[4], uint32_t rate, float mu, uint32_t frame) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  // the stage call of a streaming caller (multi_gpu.ShardedPipeline: scan -> exchange -> sweep -> deferred raycast): a raycast that is waiting rides in this
+  // scan's launch exactly as inside se_hip_integrate
+  const bool ride = p->has_pending && !p->in_frame && rate != 0 && stage_runs_integration(frame, rate) && frame_can_fuse(p);
+  InFrame guard(p, ride || p->in_frame);
   if (int r = check(p)) return r;
   if (!pose_cm || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!finite_pose(pose_cm, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
@@ -869,7 +875,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   // se_hip_set_exchange): whoever consumes that list is told "scan stream" by se_hip_scan_overlaps().
   const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
   // r04: a deferred raycast of the previous se_hip_frame call is waiting -> this scan rides in its launch, on the main stream (k_raycast_scan)
-  const bool fuse_now = p->has_pending && p->in_frame && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1;
+  const bool fuse_now = p->has_pending && p->in_frame && p->overlap && !p->stats && p->shard_world <= 1;
   // (se_hip_frame_tracked: the main stream still holds the tail of the ICP's last launch, but there is no previous raycast to hide the scan under)
   const bool chain = p->scan_on_main_once && !p->sharded && !caller_list && p->xgather == nullptr;
   p->scan_on_main_once = false;
@@ -905,7 +911,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
     if (int r = launch_raycast_scan(p, ms, a, scan_wgs)) return r;
     p->occ_commit_due = true;
     if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
-    if (!sdf) { if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r; }
+    if (!sdf && !a.sharded) { if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r; }   // (sharded: se_hip_alloc_commit, over every rank's list)
     HIP_TRY(hipGetLastError());
     return 1;
   }
@@ -950,6 +956,8 @@ int se_hip_new_keys_device(se_hip_pipeline* p, uint64_t** device_list, int64_t* 
 }
 
 int se_hip_set_new_keys_buffer(se_hip_pipeline* p, uint64_t* device_list, int64_t capacity_words) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");
+  InFrame guard(p);   // (a deferred raycast does not care where the next scan writes its list)
   if (int r = check(p)) return r;
   if (device_list && capacity_words < 2) return fail(SE_HIP_E_INVALID, "key buffer too small");
   p->map.newkeys = device_list ? (unsigned long long*)device_list : p->newkeys_own;
@@ -975,6 +983,11 @@ int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_
     HIP_TRY(hipEventRecord(p->ev_scan, p->side));
     p->scan_pending = true;
     p->occ_lists = OccLists{lists, nlists, (long long)stride_words};
+  } else if (p->occ_commit_due && !p->scan_pending && !p->upload_on_side) {
+    // the scan rode in the previous raycast's launch on the main stream (k_raycast_scan) and left the bits of its own keys to the sweep, which is still
+    // to come: no k_occ_commit launch between all-gather and sweep.  The peers' keys get their bits here (that raycast is over: stream order).
+    ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
+    hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->stream, p->map, lists, nlists, (long long)stride_words);
   } else {
     if (int r = join_scan(p)) return r;
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
@@ -1159,9 +1172,10 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
 // workgroups inherit the raycast's register and LDS footprint and no longer slip into the gaps (1280x960 -> 2048^3: 356 us fused against 285 us side by
 // side, profiles/r04p_march_skip_ab.log), so larger images keep the two-queue schedule.
 static bool frame_can_fuse(se_hip_pipeline* p) {
-  const bool caller_list = p->map.newkeys != p->newkeys_own && p->map.newkeys != p->newkeys_own2;
   const int ray_pairs = (((p->cfg.width + SE_TILE_W - 1) / SE_TILE_W) * ((p->row_end - p->row_begin + SE_TILE_H - 1) / SE_TILE_H) + 1) / 2;
-  return p->fuse && !p->ptrs_exposed && p->overlap && !p->sharded && !caller_list && p->xgather == nullptr && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
+  // (r05: row-sharded replicas and handles whose key list goes into an exchange ride along too -- the all-gather and the commit of the gathered lists
+  // then follow the fused launch on the main stream, se_hip_alloc_exchange / se_hip_alloc_commit; opt-in like everything here)
+  return p->fuse && !p->ptrs_exposed && p->overlap && !p->stats && p->shard_world <= 1 && ray_pairs <= 10 * p->n_cus;
 }
 int se_hip_set_streaming(se_hip_pipeline* p, int32_t on) {
   if (int r = check(p)) return r;   // (switching off launches an outstanding raycast first)

@@ -139,11 +139,23 @@ class ShardedPipeline:
         if self.exchange:
             import torch.distributed as dist
             self.gloo = dist.get_backend(group) == "gloo"
-            # scan + collective are ordered on the stream that is current now (the collective is issued
-            # without a stream context switch per frame); the sweep and the raycast get a stream of their own
+            # scan + collective are ordered on one stream, the sweep and the raycast get a stream of their own.  That stream must have a
+            # handle the library can launch on: torch's default stream is the legacy null stream (handle 0, which se_hip_set_scan_stream reads as
+            # "make your own") -- a scan on the library's own stream and a torch copy / collective on the default stream are not ordered at all
+            # (r05: tests/test_gpu_sharded.py::test_two_ranks_on_one_gpu_stream_frames_without_synchronising lost 34 of 10 534 blocks that way;
+            # the direct RCCL path issues its all-gather from C on the scan's stream and was not affected)
             self.xs = torch.cuda.current_stream(dev)
+            if self.xs.cuda_stream == 0:
+                cur = self.xs
+                self.xs = torch.cuda.Stream(dev)
+                self.xs.wait_stream(cur)
+                self.main = self.xs
             if self.p.scan_overlaps():
-                self.main = torch.cuda.Stream(dev)
+                if not streaming:
+                    self.main = torch.cuda.Stream(dev)
+                # streaming (the one-queue schedule with an exchange): raycast(f) + scan(f+1) are one launch on the main stream, the all-gather, the
+                # commit and the sweep follow on it -- scan stream = main stream, so that the scans that do not ride in a raycast's launch (frames
+                # 0..3, a frame behind any call that launched the held-back raycast) are ordered with torch's copies / collectives as well
                 self.p.set_scan_stream(self.xs.cuda_stream)
             # else (pooled bricks / overlap switched off): the scan runs on the main stream, so everything,
             # the collective included, is ordered on the one current stream
@@ -151,8 +163,10 @@ class ShardedPipeline:
             self._pg = pg if (not self.gloo and hasattr(pg, "_allgather_base")) else None
             self.direct = (not self.gloo) and self._direct_rccl(pg, dev)
         self.p.set_stream(self.main.cuda_stream)
-        if streaming and not self.exchange:
-            self.p.set_streaming(True)    # single replica streaming frames: the one-queue schedule (include/se_hip.h, se_hip_set_streaming)
+        self.streaming = False
+        if streaming:
+            # the one-queue schedule (include/se_hip.h, se_hip_set_streaming): a frame's raycast is launched with the next frame's scan
+            self.streaming = bool(self.p.set_streaming(True))
         # Sharded sweep (SURVEY 8e option 4; off by default, DESIGN.md section 7 has the price): owner-computes integration
         # + an all-gather of the updated bricks instead of every replica sweeping every block.
         self.shard_sweep = bool(shard_sweep) and world > 1
@@ -270,30 +284,37 @@ class ShardedPipeline:
                 send, recv = self._views[words]
                 if self.gloo:
                     # dry-run transport (several ranks sharing one GPU, no RCCL): stage through the host
-                    host = exchange_key_lists(send.cpu(), self.world, self.group)   # .cpu(): ordered on xs, blocks the host
-                    recv.copy_(host)
+                    with self.torch.cuda.stream(self.xs):
+                        host = exchange_key_lists(send.cpu(), self.world, self.group)   # .cpu(): ordered on xs, blocks the host
+                        recv.copy_(host)
                 elif self.direct:
                     p.alloc_exchange(recv.data_ptr(), words)
                     p.integrate_sweep(k, integration_rate, mu, frame)
                     if self.shard_sweep:
                         self._exchange_bricks()
-                    p.raycasting(k, mu, frame)
-                    self._images_full = self.world == 1
+                    self._raycast(k, mu, frame)
                     return ran
                 else:
-                    if self._pg is not None:
-                        self._pg._allgather_base(recv, send).wait()   # wait() = the issuing stream waits, not the host
-                    else:
-                        import torch.distributed as dist
-                        dist.all_gather_into_tensor(recv, send, group=self.group)
+                    with self.torch.cuda.stream(self.xs):
+                        if self._pg is not None:
+                            self._pg._allgather_base(recv, send).wait()   # wait() = the issuing stream waits, not the host
+                        else:
+                            import torch.distributed as dist
+                            dist.all_gather_into_tensor(recv, send, group=self.group)
                     # no stream join here: se_hip_alloc_commit fences the scan stream (= xs) itself
                 p.alloc_commit(recv.data_ptr(), self.world, words)
             p.integrate_sweep(k, integration_rate, mu, frame)
             if self.shard_sweep:
                 self._exchange_bricks()
-        p.raycasting(k, mu, frame)
-        self._images_full = self.world == 1
+        self._raycast(k, mu, frame)
         return ran
+
+    def _raycast(self, k, mu, frame):
+        if self.streaming:
+            self.p.raycasting_deferred(k, mu, frame)    # launched with the next frame's scan, or by whatever call comes first
+        else:
+            self.p.raycasting(k, mu, frame)
+        self._images_full = self.world == 1
 
     def close(self):
         self.p.close()

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("field,mu,R,H", [(SDF, 0.1, 2, 120), (SDF, 0.1, 4, 120), (OFUSION, 0.02, 2, 120), (SDF, 0.1, 8, 116), (OFUSION, 0.02, 8, 116),
                                           (SDF, 0.1, 4, -120), (OFUSION, 0.02, 3, -120)],
                          ids=["sdf-2", "sdf-4", "ofusion-2", "sdf-8-odd-height", "ofusion-8-odd-height", "sdf-4-stress", "ofusion-3-stress"])
-def test_sharded_replicas_equal_single(field, mu, R, H):
+@pytest.mark.parametrize("streaming", [False, True], ids=["two-queue", "one-queue"])
+def test_sharded_replicas_equal_single(field, mu, R, H, streaming):
     # H = 116: 14.5 raycast tiles of 8 rows -> shards of 1 or 2 tile rows, the last one ending in a half tile
     # H < 0: the ICL-like stress stream (r03), every 3rd frame of its path: blocks leave the frustum of one rank's rows and are woken
     # by another rank's rays, hundreds of new keys per frame and rank, samples outside the volume
@@ -50,6 +51,9 @@ def test_sharded_replicas_equal_single(field, mu, R, H):
     send = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in range(R)]
     for r in range(R):
         reps[r].set_new_keys_buffer(send[r].data_ptr(), words, keepalive=send[r])
+        # one-queue (r05): a replica's raycast of frame f is held back and launched with its scan of frame f+1 (k_raycast_scan over the replica's rows,
+        # the scan writing the send buffer); the gathered lists are committed behind that launch
+        assert reps[r].set_streaming(streaming) == streaming
     for f in range(frames):
         depth, pose = stream.depth(f), stream.pose(f)
         single.set_depth(depth); single.setPose(pose)
@@ -65,9 +69,17 @@ def test_sharded_replicas_equal_single(field, mu, R, H):
         for p in reps:
             p.alloc_commit(recv.data_ptr(), R, words)
             p.integrate_sweep(stream.k, 1, mu, f)
-            p.raycasting(stream.k, mu, f)
+            if streaming:
+                assert p.raycasting_deferred(stream.k, mu, f) == (f > 2)
+                assert p.launch_counts()["pending"] == (1 if f > 2 else 0)
+            else:
+                p.raycasting(stream.k, mu, f)
+        if not streaming:
+            for p in reps:
+                p.sync()
+    if streaming:
         for p in reps:
-            p.sync()
+            assert p.launch_counts()["fused"] == frames - 4 and p.launch_counts()["raycast"] == frames - 4    # (the last raycast is still held back)
     c, x, y, a = single.blocks()
     code, side, nx, ny = single.nodes()
     v, n = single.vertex_normal()
@@ -198,8 +210,9 @@ def test_key_list_overflow_is_reported_on_the_frame_path():
     p.close()
 
 
+@pytest.mark.parametrize("streaming", [False, True], ids=["two-queue", "one-queue"])
 @pytest.mark.parametrize("exchange", ["direct", "torch"])
-def test_sharded_pipeline_stream_plan_single_rank_rccl(exchange, monkeypatch):
+def test_sharded_pipeline_stream_plan_single_rank_rccl(exchange, streaming, monkeypatch):
     """ShardedPipeline with a one-rank RCCL group: the exchange stream, the all-gather call and the
     commit of the gathered list run exactly as with R > 1 (the own list is committed again, a no-op);
     the result must equal the plain pipeline's."""
@@ -220,14 +233,17 @@ def test_sharded_pipeline_stream_plan_single_rank_rccl(exchange, monkeypatch):
         # "torch": torch.distributed's collective (the fallback)
         if exchange == "torch":
             monkeypatch.setenv("SE_EXCHANGE", "torch")
-        sp = ShardedPipeline((W, H), N, dim, SDF, 0, 1, 0, exchange_always=True)
-        assert sp.direct == (exchange == "direct")
+        sp = ShardedPipeline((W, H), N, dim, SDF, 0, 1, 0, exchange_always=True, streaming=streaming)
+        assert sp.direct == (exchange == "direct") and sp.streaming == streaming
         depth = torch.from_numpy(np.stack([stream.depth(f) for f in range(frames)])).cuda()
         for f in range(frames):
             single.set_depth_device(depth[f].data_ptr()); single.setPose(stream.pose(f))
             single.integration(stream.k, 1, mu, f)
             single.raycasting(stream.k, mu, f)
             sp.frame(depth[f].data_ptr(), stream.pose(f), stream.k, mu, f)
+        if streaming:   # raycast(f) + scan(f+1) were one launch, the ncclAllGather followed it on the same stream
+            n = sp.p.launch_counts()
+            assert n["fused"] == frames - 4 and n["pending"] == 1, n
         torch.cuda.synchronize()
         # the collective really moved the list (committing one's own list again would pass without it)
         w = sp._words
@@ -418,3 +434,78 @@ def test_sharded_tracking_sees_the_full_images(R, H):
             p.sync()
     for p in [single] + reps:
         p.close()
+
+
+def _two_rank_worker(rank, world, port, streaming, exchange, q):
+    """One of two processes sharing GPU 0 (gloo transport, as bench.py's dry run of --gpus 2): streams the frames through ShardedPipeline without
+    ever synchronising, then compares its replica with an unsharded pipeline fed the same frames."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from supereight_amd.multi_gpu import ShardedPipeline
+        W, H, N, dim, mu, frames = 320, 240, 512, 4.8, 0.1, 30
+        s = SyntheticStream(W, H, dim)
+        depth = torch.from_numpy(np.stack([s.depth(f) for f in range(frames)])).cuda()
+        sp = ShardedPipeline((W, H), N, dim, SDF, rank, world, 0, streaming=streaming)
+        assert sp.gloo and sp.streaming == streaming
+        for f in range(frames):
+            sp.frame(depth[f].data_ptr(), s.pose(f), s.k, mu, f)        # no synchronisation between frames
+        fused = sp.p.launch_counts()["fused"]
+        torch.cuda.synchronize()
+        single = DenseSLAMPipeline((W, H), N, dim, field_type=SDF)
+        for f in range(frames):
+            single.set_depth_device(depth[f].data_ptr()); single.setPose(s.pose(f))
+            single.integration(s.k, 1, mu, f)
+            single.raycasting(s.k, mu, f)
+        c, x, y, a = single.blocks()
+        rc, rx, ry, ra = sp.p.blocks()
+        b, e = sp.rows
+        v, n = single.vertex_normal()
+        rv, rn = sp.p.vertex_normal()
+        res = {"rank": rank, "fused": fused, "blocks": [int(len(c)), int(len(rc))],
+               "same_set": bool(rc.shape == c.shape and (rc == c).all())}
+        if res["same_set"]:
+            res["x_mismatch"] = int((rx.view(np.uint32) != x.view(np.uint32)).sum())
+            res["y_mismatch"] = int((ry.view(np.uint32) != y.view(np.uint32)).sum())
+            res["active_mismatch"] = int((ra != a).sum())
+        res["image_mismatch"] = int((rv[b:e].view(np.uint32) != v[b:e].view(np.uint32)).sum() + (rn[b:e].view(np.uint32) != n[b:e].view(np.uint32)).sum())
+        sp.close(); single.close()
+        q.put(res)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:     # (a worker that dies silently would leave the parent waiting)
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise ex
+
+
+@pytest.mark.parametrize("streaming", [False, True], ids=["two-queue", "one-queue"])
+def test_two_ranks_on_one_gpu_stream_frames_without_synchronising(streaming):
+    """The N = 2 frame loop exactly as bench.py --gpus 2 drives it (two processes, every frame enqueued behind the last, the key lists exchanged
+    through torch.distributed) -- on one GPU with the gloo transport, which is what this box offers.  The in-process replica tests above separate
+    the stages with synchronisations; here nothing does, so the stream ordering between the library's launches and torch's copies / collectives is
+    what is tested.  Both replicas must end with the unsharded pipeline's map and their rows of its last raycast, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, streaming, "gloo", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for res in sorted(out, key=lambda r: r["rank"]):
+        print(res)
+        assert "error" not in res, res["error"]
+        assert res["same_set"] and res["blocks"][0] > 5000, res
+        assert res["x_mismatch"] == 0 and res["y_mismatch"] == 0 and res["active_mismatch"] == 0 and res["image_mismatch"] == 0, res
+        assert res["fused"] == (30 - 4 if streaming else 0), res
