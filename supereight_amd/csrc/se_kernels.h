@@ -1735,7 +1735,10 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
   bool done = false;
   // (r05, measured and dropped: 4 samples per round trip instead of 2 from the 3rd / 6th batch of a ray on, outside the truncation band -- aimed at the
   // silhouette rays whose 12-23 round trips end the launch: fused launch 43.2 / 41.8 instead of 35.8 us at 512^3, 75 / 73 instead of 71 us at 1024^3,
-  // profiles/r05w_deep_ab.log.  Every earlier attempt to trade instructions for round trips in this loop lost too: profiles/DESIGN_r01-r04.md 4.4)
+  // profiles/r05w_deep_ab.log.  Nor does fetching the SECOND sample's eight corners with the batch while the march creeps along at `step` inside the band (a
+  // grazing ray consumes both samples and wants both interpolated: two round trips per batch become one): 36.9 / 36.3 -> 36.7 / 36.8 us at 512^3, 69.0 / 68.5
+  // -> 72.4 / 71.8 us at 1024^3, profiles/r05ae_prefetch1_ab.log.  Every earlier attempt to trade instructions for round trips in this loop lost too:
+  // profiles/DESIGN_r01-r04.md 4.4)
   bool band = f_t < 1.f;   // the last value seen was inside the truncation band: the next sample probably wants its interpolated value
   bool unobs = false;      // the last consumed sample had weight 0 (unobserved space)
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
