@@ -86,7 +86,8 @@ int se_hip_set_stream(se_hip_pipeline* p, void* hip_stream);
 /* The stream the allocation scan (se_hip_alloc_scan) is launched on when it overlaps the previous
  * frame's raycast.  The multi-GPU driver passes the stream its
  * all-gather of the key lists is ordered on, so that scan + exchange of frame f+1 hide behind the
- * raycast of frame f.  NULL = a stream owned by the handle (the default). */
+ * raycast of frame f.  NULL = a stream owned by the handle (the default) -- NOT the legacy default stream: a caller whose collective runs on
+ * stream 0 (PyTorch's default stream is handle 0) must create a real stream for it and pass that, or scan and collective are unordered. */
 int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream);
 /* 1 if the key list of se_hip_alloc_scan is produced on the scan stream (overlap on: the default), 0 if on the main
  * stream like every other stage -- in which case work ordered with the scan (an all-gather of its list) belongs on the main
