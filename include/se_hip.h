@@ -133,7 +133,8 @@ int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m);
 int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_depth_mm, int32_t in_w, int32_t in_h);
 /* Zero-copy: integrate from a depth image already resident in HBM (width*height floats).  The buffer is read by the
  * allocation scan and by the integration sweep of the frame: it must stay untouched until that sweep has finished
- * (se_hip_sync, or work ordered behind se_hip_integrate on the handle's stream). */
+ * (se_hip_sync, or work ordered behind se_hip_integrate on the handle's stream).  It must also be COMPLETE when the handle's streams get to
+ * it: a producer kernel on another stream is not ordered with them -- hand the handle the producer's stream (se_hip_set_stream) or wait for it. */
 int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m);
 
 /* ---- bool DenseSLAMSystem::integration(const Vector4f& k, unsigned integration_rate, float mu,
