@@ -2068,6 +2068,8 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
 
 // One thread per pixel; a wave covers an 8x8 pixel tile so that its rays stay in neighbouring
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
+// (r05, fused launch with a 6th / 7th wave slot per SIMD so that scan waves start beside the raycast's first round instead of behind it: 73 / 70 VGPRs without
+// scratch for the SDF instantiation, +-0 at 512^3 on both streams; the OFusion instantiation spills: 89 -> 114 / 160 us.  profiles/r05ag_occ_ab.log)
 #ifdef SE_RAY_WAVES_PER_EU   // experiment: force the register budget of N waves per SIMD (8 -> 64 VGPRs)
 #define SE_RAY_OCC __attribute__((amdgpu_waves_per_eu(SE_RAY_WAVES_PER_EU, SE_RAY_WAVES_PER_EU)))
 #else
