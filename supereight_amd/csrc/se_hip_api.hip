@@ -152,6 +152,7 @@ struct se_hip_pipeline {
   int leaf_level = 0, max_level = 0;
   size_t tab_entries = 0;
   size_t occ_words = 0, lbits_words = 0, cbits_words = 0, fbits_words = 0;
+  bool of_leap = true;         // OFusion march: leap over block-free space (se_of_leap); SE_HIP_OF_LEAP=0 turns it off (A/B knob, same results)
   int beam = 2;                // raycast: beam start (se_beam_start): 0 off, 1 coarse stage only, 2 both stages; SE_HIP_BEAM (A/B knob: results are the same either way)
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
@@ -334,6 +335,10 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.beam_inv_cell = (float)(1 << m.clevel) / m.dim;
   a.beam_dt = std::max(0.5f * a.beam_cell, (a.farp - a.nearp) / 64.f);
   a.inv_dim = 1.f / m.dim;
+  // OFusion march: leap over block-free space on the dilated block grid (fbits; for leaf levels <= 5 the coarse grid IS the block grid)
+  a.leap_bits = !p->of_leap ? nullptr : m.fbits ? m.fbits : (m.clevel == m.leaf_level ? m.cbits : nullptr);
+  a.leap_level = m.leaf_level;
+  a.leap_dt = 0.9f * a.beam_cellf;
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
   // one workgroup per tile pair, in whole rounds over the compute units (workgroups of the last round beyond the list idle)
@@ -503,6 +508,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_ICP_LOOKAHEAD")) p->icp_lookahead = std::max(0, std::atoi(ev));   // A/B knob (0: every ICP iteration enqueued up front)
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
   if (const char* ev = std::getenv("SE_HIP_BEAM")) p->beam = std::max(0, std::min(2, std::atoi(ev)));   // A/B + test knob
+  if (const char* ev = std::getenv("SE_HIP_OF_LEAP")) p->of_leap = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SE_HIP_IEEE_SWEEP")) p->ieee_sweep = std::atoi(ev) != 0;       // A/B + test knob: the sweep instantiation with the compiler's divisions
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob

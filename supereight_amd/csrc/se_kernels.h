@@ -990,6 +990,11 @@ struct RayArgs {
   int beam;          // 0 off, 1 coarse stage, 2 coarse + fine stage
   float beam_dt, beam_cell, beam_inv_cell, inv_dim;
   float beam_dt2, beam_cellf, beam_inv_cellf;     // second stage: the block grid itself (DevMap::fbits)
+  // OFusion march: leap over block-free space (se_of_leap; results do not depend on it): the block grid dilated by one block, its level, the spacing of the
+  // check points along the ray (0.9 block edges); leap_bits = nullptr switches it off
+  const uint32_t* leap_bits;
+  int leap_level;
+  float leap_dt;
   // Scheduling (results do not depend on it).  tile_cost[] = cost of every wave tile (8x8 pixels) in the previous
   // raycast launch, trips + 5 * march batches of its slowest ray.  All waves of a 640x480 launch are resident from the
   // first microsecond, every SIMD works through the 4-5 tiles the dispatcher gives it, and the launch lasts as long as the
@@ -1904,6 +1909,49 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
     hx = r.x; hy = r.y; hz = r.z; hw = t;
   }
 }
+// ---- OFusion march: leaping over block-free space (r05) -----------------------------------------------------------------------------------
+// raycast(Volume<OFusion>) steps one voxel at a time from the first leaf to the far plane (bfusion/rendering_impl.hpp:44-52), whatever it walks through: a
+// ray that enters the blocks around a foreground object, misses the object and hits the wall two metres behind it takes 240 steps through space in which
+// no block exists -- every one of them a get() that returns initValue() (y = 0: "no interp, f_tt unchanged, f_t = f_tt, t += step").  On the per-wave
+// timeline (profiles/r05ah_wave_timelines.txt) these rays ARE the launch: 9 % of the waves run 25-32 batches of eight such samples, 45 us after the other
+// 91 % are done.  A step through block-free space has no effect but the float addition t += step, so those additions are all that is done for it: check
+// points 0.9 block edges apart on the ray are asked of the block grid dilated by one block (leap_bits: a clear bit = no block within one block of that
+// cell, so every point within a block edge of a clear check point lies in a block that does not exist), eight per round trip, as long as they come back
+// clear; the samples up to one step short of the last clear check point are consumed by K additions and f_t = f_tt.  Conservative: a bit set concurrently
+// by the next frame's scan shortens the leap, and a block that appears behind the test holds initValue() in every voxel (the argument of
+// se_march_skip).  Returns the number of samples consumed; `t` is advanced exactly as the loop would have advanced it.
+#ifndef SE_OF_LEAP
+#define SE_OF_LEAP 1
+#endif
+__device__ __forceinline__ int se_of_leap(const RayArgs& a, f3 org, f3 dir, float tfar, float& t) {
+  constexpr int M = 8;
+  const int F = a.leap_level;
+  float t_clear = t;
+  for (int it = 0; it < 16; ++it) {
+    uint32_t idx[M], w[M];
+    bool in[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const f3 q = f3_add(org, f3_scale_r(dir, t_clear + (float)j * a.leap_dt));
+      const int cx = se_cvt_flr(q.x * a.beam_inv_cellf), cy = se_cvt_flr(q.y * a.beam_inv_cellf), cz = se_cvt_flr(q.z * a.beam_inv_cellf);
+      in[j] = (uint32_t)(cx | cy | cz) < (1u << F);     // outside the volume counts as "not clear": the march ends at the volume's face anyway
+      idx[j] = in[j] ? (((uint32_t)cz << (2 * F)) | ((uint32_t)cy << F) | (uint32_t)cx) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) w[j] = a.leap_bits[idx[j] >> 5];
+    int n = 0;
+    bool run = true;
+#pragma unroll
+    for (int j = 0; j < M; ++j) { run = run && in[j] && !((w[j] >> (idx[j] & 31u)) & 1u); n += run ? 1 : 0; }
+    if (n == 0) break;
+    t_clear += (float)(n - 1) * a.leap_dt;
+    if (n < M || !(t_clear < tfar)) break;
+  }
+  // samples t, t + step, ... (accumulated in float as the loop does) up to one step short of t_clear: at most a few hundred additions
+  const int K = (int)((t_clear - t) * a.inv_voxel) - 1;
+  for (int i = 0; i < K; ++i) t += a.step;
+  return K > 0 ? K : 0;
+}
 template <bool STATS>
 __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
                                                       BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
@@ -1914,10 +1962,14 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t <= 0.f)) return;
-  bool done = false;
+  bool done = false, quiet = false;   // quiet: no sample of the last batch was observed
   SePCache pc = {0xFFFFFFFFu, 0u};
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
+    if (SE_OF_LEAP && quiet && a.leap_bits) {
+      if (se_of_leap(a, org, dir, tfar, t) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
+    }
+    quiet = true;
     float tt[SE_SPEC_OF];
     f3 q[SE_SPEC_OF];
     SePSample sm[SE_SPEC_OF];
@@ -1938,6 +1990,7 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
       if (STATS) ++rc.n_get;
       const float dx = sm[i].e ? qx[i] : fc.init_x, dy = sm[i].e ? qy[i] : fc.init_y;
       if (dx > -100.f && dy > 0.f) {
+        quiet = false;
         c.bx = sm[i].bx; c.by = sm[i].by; c.bz = sm[i].bz; c.e = sm[i].e;
         f_tt = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
         if (STATS) ++rc.n_interp;
@@ -1967,9 +2020,13 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t <= 0.f)) return;
-  bool done = false;
+  bool done = false, quiet = false;   // quiet: no sample of the last batch was observed
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
+    if (SE_OF_LEAP && quiet && a.leap_bits) {
+      if (se_of_leap(a, org, dir, tfar, t) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
+    }
+    quiet = true;
     float tt[SE_SPEC_OF];
     f3 q[SE_SPEC_OF];
     SeSample<O32> sm[SE_SPEC_OF];
@@ -1990,6 +2047,7 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
       if (STATS) ++rc.n_get;
       const float dx = sm[i].in ? qx[i] : fc.init_x, dy = sm[i].in ? qy[i] : fc.init_y;
       if (dx > -100.f && dy > 0.f) {
+        quiet = false;
         f_tt = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, q[i]), c);
         if (STATS) ++rc.n_interp;
       }
