@@ -1916,40 +1916,42 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
 // timeline (profiles/r05ah_wave_timelines.txt) these rays ARE the launch: 9 % of the waves run 25-32 batches of eight such samples, 45 us after the other
 // 91 % are done.  A step through block-free space has no effect but the float addition t += step, so those additions are all that is done for it: check
 // points 0.9 block edges apart on the ray are asked of the block grid dilated by one block (leap_bits: a clear bit = no block within one block of that
-// cell, so every point within a block edge of a clear check point lies in a block that does not exist), eight per round trip, as long as they come back
+// cell, so every point within a block edge of a clear check point lies in a block that does not exist), sixteen per round trip, as long as they come back
 // clear; the samples up to one step short of the last clear check point are consumed by K additions and f_t = f_tt.  Conservative: a bit set concurrently
 // by the next frame's scan shortens the leap, and a block that appears behind the test holds initValue() in every voxel (the argument of
 // se_march_skip).  Returns the number of samples consumed; `t` is advanced exactly as the loop would have advanced it.
 #ifndef SE_OF_LEAP
 #define SE_OF_LEAP 1
 #endif
-__device__ __forceinline__ int se_of_leap(const RayArgs& a, f3 org, f3 dir, float tfar, float& t) {
-  constexpr int M = 8;
+__device__ __forceinline__ int se_of_leap(const RayArgs& a, f3 org, f3 dir, float tfar, float& t, float& hold) {
+  constexpr int M = 12;
   const int F = a.leap_level;
   float t_clear = t;
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < 8; ++it) {
     uint32_t idx[M], w[M];
-    bool in[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       const f3 q = f3_add(org, f3_scale_r(dir, t_clear + (float)j * a.leap_dt));
       const int cx = se_cvt_flr(q.x * a.beam_inv_cellf), cy = se_cvt_flr(q.y * a.beam_inv_cellf), cz = se_cvt_flr(q.z * a.beam_inv_cellf);
-      in[j] = (uint32_t)(cx | cy | cz) < (1u << F);     // outside the volume counts as "not clear": the march ends at the volume's face anyway
-      idx[j] = in[j] ? (((uint32_t)cz << (2 * F)) | ((uint32_t)cy << F) | (uint32_t)cx) : 0u;
+      const bool in = (uint32_t)(cx | cy | cz) < (1u << F);     // outside the volume counts as "not clear": the march ends at the volume's face anyway
+      idx[j] = in ? (((uint32_t)cz << (2 * F)) | ((uint32_t)cy << F) | (uint32_t)cx) : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int j = 0; j < M; ++j) w[j] = a.leap_bits[idx[j] >> 5];
+    for (int j = 0; j < M; ++j) w[j] = idx[j] != 0xFFFFFFFFu ? a.leap_bits[idx[j] >> 5] : 0xFFFFFFFFu;
     int n = 0;
     bool run = true;
 #pragma unroll
-    for (int j = 0; j < M; ++j) { run = run && in[j] && !((w[j] >> (idx[j] & 31u)) & 1u); n += run ? 1 : 0; }
+    for (int j = 0; j < M; ++j) { run = run && !((w[j] >> (idx[j] & 31u)) & 1u); n += run ? 1 : 0; }
+    if (n < M) hold = t_clear + (float)n * a.leap_dt;      // the first check point that is not clear: no further test before the march has got there
     if (n == 0) break;
     t_clear += (float)(n - 1) * a.leap_dt;
     if (n < M || !(t_clear < tfar)) break;
   }
   // samples t, t + step, ... (accumulated in float as the loop does) up to one step short of t_clear: at most a few hundred additions
   const int K = (int)((t_clear - t) * a.inv_voxel) - 1;
-  for (int i = 0; i < K; ++i) t += a.step;
+  int i = 0;
+  for (; i + 8 <= K; i += 8) { t += a.step; t += a.step; t += a.step; t += a.step; t += a.step; t += a.step; t += a.step; t += a.step; }
+  for (; i < K; ++i) t += a.step;
   return K > 0 ? K : 0;
 }
 template <bool STATS>
@@ -1963,11 +1965,12 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
   float f_tt = 0;
   if (!(f_t <= 0.f)) return;
   bool done = false, quiet = false;   // quiet: no sample of the last batch was observed
+  float leap_hold = 0.f;              // no leap test before t has reached this value (the check point the last test found blocked)
   SePCache pc = {0xFFFFFFFFu, 0u};
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
-    if (SE_OF_LEAP && quiet && a.leap_bits) {
-      if (se_of_leap(a, org, dir, tfar, t) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
+    if (SE_OF_LEAP && quiet && a.leap_bits && t >= leap_hold) {
+      if (se_of_leap(a, org, dir, tfar, t, leap_hold) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
     }
     quiet = true;
     float tt[SE_SPEC_OF];
@@ -2021,10 +2024,11 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
   float f_tt = 0;
   if (!(f_t <= 0.f)) return;
   bool done = false, quiet = false;   // quiet: no sample of the last batch was observed
+  float leap_hold = 0.f;              // no leap test before t has reached this value (the check point the last test found blocked)
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
-    if (SE_OF_LEAP && quiet && a.leap_bits) {
-      if (se_of_leap(a, org, dir, tfar, t) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
+    if (SE_OF_LEAP && quiet && a.leap_bits && t >= leap_hold) {
+      if (se_of_leap(a, org, dir, tfar, t, leap_hold) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
     }
     quiet = true;
     float tt[SE_SPEC_OF];
@@ -2128,11 +2132,13 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
 // blocks.  Output: packed float3 vertex / normal images (se::Image<Eigen::Vector3f>).
 // (r05, fused launch with a 6th / 7th wave slot per SIMD so that scan waves start beside the raycast's first round instead of behind it: 73 / 70 VGPRs without
 // scratch for the SDF instantiation, +-0 at 512^3 on both streams; the OFusion instantiation spills: 89 -> 114 / 160 us.  profiles/r05ag_occ_ab.log)
-#ifdef SE_RAY_WAVES_PER_EU   // experiment: force the register budget of N waves per SIMD (8 -> 64 VGPRs)
-#define SE_RAY_OCC __attribute__((amdgpu_waves_per_eu(SE_RAY_WAVES_PER_EU, SE_RAY_WAVES_PER_EU)))
-#else
-#define SE_RAY_OCC
+// Register budget of the dense-grid instantiations: 5 waves per SIMD (<= 96 VGPRs), stated instead of hoped for -- 640x480 is 5 120 waves, exactly five per
+// SIMD, and an instantiation that lands on 97 registers (the OFusion march did, depending on an unrelated unroll factor) runs a second round of workgroups.
+// The pooled instantiations keep what the compiler gives them (135 VGPRs for OFusion: forcing 96 means scratch in the march).
+#ifndef SE_RAY_WAVES_PER_EU
+#define SE_RAY_WAVES_PER_EU 5   // (experiments: 6 / 7 / 8, profiles/r05ag_occ_ab.log, profiles/DESIGN_r01-r04.md)
 #endif
+#define SE_RAY_OCC __attribute__((amdgpu_waves_per_eu(DENSE ? SE_RAY_WAVES_PER_EU : 1)))
 // The kernel's body (k_raycast_scan runs it for the first workgroups of a fused launch): `bid` = workgroup index within the raycast's grid.
 template <bool OFUSION, bool STATS, bool DENSE, bool SHALLOW, bool O32>   // O32: the voxel planes span <= 4 GiB (dense 512^3): 32-bit byte offsets
 __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a, float* __restrict__ vertex, float* __restrict__ normal, uint32_t* smem, const int bid) {
