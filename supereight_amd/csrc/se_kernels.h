@@ -2012,6 +2012,10 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
 
 // raycast(const Volume<OFusion>&, ...) (se_denseslam/src/bfusion/rendering_impl.hpp:35-68) on the dense grid with the lean addressing
 // above; same float operations in the same order as the generic form in se_cast_ray
+// (r05, measured and dropped: once the values of a batch are here, fetching the interpolation corners of the samples that want them two / four samples per
+// round trip instead of one -- aimed at batches inside observed blocks, 3.6 us each on the per-wave timeline once the leap had removed the empty-space
+// batches: 84 / 164 bytes of scratch per lane under the 96-register budget and interpolations behind a hit: fused launch 72.5 -> 107 / 115 us.
+// profiles/r05ak_of_group_ab.log)
 template <bool STATS, bool O32>
 __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
