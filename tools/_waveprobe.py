@@ -11,11 +11,10 @@ p = DenseSLAMPipeline((W, H), N, dim, field_type=field, streaming=True)
 k = np.ascontiguousarray(s.k, np.float32)
 for f in range(F):
     p.frame(depth[f].data_ptr(), to_colmajor(s.pose(f)), k, mu, f)
-p.sync()
-p.raycasting(k, mu, F)
-p.sync()
-a = np.fromfile(os.environ["SE_HIP_WLOG"], dtype=np.uint64).reshape(-1, 4)
-a = a[a[:, 1] > 0]
+torch.cuda.synchronize()    # (no se_hip call: the file holds the log of the last-but-one fused launch, dumped when the last one was enqueued)
+raw = np.fromfile(os.environ["SE_HIP_WLOG"], dtype=np.uint64).reshape(-1, 4)
+a = raw[:16384]; a = a[a[:, 1] > 0]
+sc = raw[16384:]; sc = sc[sc[:, 1] > 0]
 t0 = a[:, 0].astype(np.int64); t1 = a[:, 1].astype(np.int64)
 base = t0.min(); st = (t0 - base) / 100.0; en = (t1 - base) / 100.0
 hw = a[:, 2] & np.uint64(0xFFFFFFFF); xcc = (a[:, 2] >> np.uint64(32)) & np.uint64(0xF)
@@ -37,3 +36,10 @@ o = np.argsort(-en)[:8]
 print("last waves (end, trips, batches):", [(round(float(en[i]), 1), int(trips[i]), int(batches[i])) for i in o])
 half = en.max() * 0.6
 print("waves alive after 60%% of the span: %d (%.1f %%)" % ((en > half).sum(), 100.0 * (en > half).mean()))
+
+if len(sc):
+    s0 = (sc[:, 0].astype(np.int64) - base) / 100.0; s1 = (sc[:, 1].astype(np.int64) - base) / 100.0
+    print("scan waves", len(sc), "start p10/p50/p90/max", round(np.percentile(s0, 10), 1), round(np.median(s0), 1), round(np.percentile(s0, 90), 1), round(s0.max(), 1),
+          "end p50/p90/max", round(np.median(s1), 1), round(np.percentile(s1, 90), 1), round(s1.max(), 1), "dur mean/max", round((s1 - s0).mean(), 1), round((s1 - s0).max(), 1))
+    ts = np.linspace(0, max(en.max(), s1.max()), 12)
+    print("resident scan waves at t:", [(round(float(t), 1), int(((s0 <= t) & (s1 > t)).sum())) for t in ts])
