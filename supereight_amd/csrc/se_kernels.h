@@ -1926,6 +1926,15 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
 #ifndef SE_OF_LEAP
 #define SE_OF_LEAP 1
 #endif
+// 0 if the dilated block grid is clear at q (no block within one block of it), non-zero if not or if q lies outside the volume
+__device__ __forceinline__ uint32_t se_leap_word(const RayArgs& a, f3 q) {
+  const int F = a.leap_level;
+  const int cx = se_cvt_flr(q.x * a.beam_inv_cellf), cy = se_cvt_flr(q.y * a.beam_inv_cellf), cz = se_cvt_flr(q.z * a.beam_inv_cellf);
+  const bool in = (uint32_t)(cx | cy | cz) < (1u << F);
+  const uint32_t idx = in ? (((uint32_t)cz << (2 * F)) | ((uint32_t)cy << F) | (uint32_t)cx) : 0u;
+  const uint32_t w = a.leap_bits[idx >> 5];        // (unconditional: issued with the batch's value loads)
+  return in ? ((w >> (idx & 31u)) & 1u) : 1u;
+}
 __device__ __forceinline__ int se_of_leap(const RayArgs& a, f3 org, f3 dir, float tfar, float& t, float& hold) {
   constexpr int M = 12;
   const int F = a.leap_level;
@@ -1945,7 +1954,7 @@ __device__ __forceinline__ int se_of_leap(const RayArgs& a, f3 org, f3 dir, floa
     bool run = true;
 #pragma unroll
     for (int j = 0; j < M; ++j) { run = run && !((w[j] >> (idx[j] & 31u)) & 1u); n += run ? 1 : 0; }
-    if (n < M) hold = t_clear + (float)n * a.leap_dt;      // the first check point that is not clear: no further test before the march has got there
+    if (n < M) hold = t_clear + (float)(n + 1) * a.leap_dt;   // one block behind the first check point that is not clear: no further test before the march has got there
     if (n == 0) break;
     t_clear += (float)(n - 1) * a.leap_dt;
     if (n < M || !(t_clear < tfar)) break;
@@ -1975,7 +1984,6 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
     if (SE_OF_LEAP && quiet && a.leap_bits && t >= leap_hold) {
       if (se_of_leap(a, org, dir, tfar, t, leap_hold) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
     }
-    quiet = true;
     float tt[SE_SPEC_OF];
     f3 q[SE_SPEC_OF];
     SePSample sm[SE_SPEC_OF];
@@ -1985,6 +1993,7 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
     for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) { q[i] = f3_add(org, f3_scale_r(dir, tt[i])); sm[i] = se_sample_pooled<false>(m, a, q[i], pc, false); }
+    quiet = (SE_OF_LEAP && a.leap_bits ? se_leap_word(a, q[SE_SPEC_OF - 1]) : 1u) == 0u;   // (see se_cast_ray_of_lean)
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) { const size_t vi = se_pooled_index(sm[i]); qx[i] = m.vx[vi]; qy[i] = m.vx[vi + 512]; }
     bool stop = false;
@@ -2037,7 +2046,6 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
     if (SE_OF_LEAP && quiet && a.leap_bits && t >= leap_hold) {
       if (se_of_leap(a, org, dir, tfar, t, leap_hold) > 0) { f_t = f_tt; if (!(t < tfar)) break; }
     }
-    quiet = true;
     float tt[SE_SPEC_OF];
     f3 q[SE_SPEC_OF];
     SeSample<O32> sm[SE_SPEC_OF];
@@ -2047,8 +2055,12 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
     for (int i = 1; i < SE_SPEC_OF; ++i) tt[i] = tt[i - 1] + stepsize;
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) { q[i] = f3_add(org, f3_scale_r(dir, tt[i])); sm[i] = se_sample_lean<O32>(m, a, q[i]); }
+    // (the leap is only tried from block-free space: the batch's last sample asks the dilated grid along with the values -- a quiet batch inside
+    // allocated, unobserved blocks would otherwise pay a test that cannot succeed, batch after batch: r05an)
+    const uint32_t lw = SE_OF_LEAP && a.leap_bits ? se_leap_word(a, q[SE_SPEC_OF - 1]) : 1u;
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) { qx[i] = A::ldx(m, sm[i].vi); qy[i] = A::ldy(m, sm[i].vi); }
+    quiet = lw == 0u;
     bool stop = false;
 #pragma unroll
     for (int i = 0; i < SE_SPEC_OF; ++i) {

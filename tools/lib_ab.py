@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 CFG = {"sdf512": (640, 480, 512, "sdf", 0.1, 60), "sdf1024": (640, 480, 1024, "sdf", 0.1, 50), "of512": (640, 480, 512, "ofusion", 0.008, 40),
        "sdf2048": (1280, 960, 2048, "sdf", 0.1, 24), "stress512": (640, 480, 512, "sdf", 0.1, 60), "stress1024": (640, 480, 1024, "sdf", 0.1, 50),
        "pooled512": (640, 480, 512, "sdf", 0.1, 60), "pooled1024": (640, 480, 1024, "sdf", 0.1, 50), "pooled2048": (1280, 960, 2048, "sdf", 0.1, 24),
-       "pooledstress512": (640, 480, 512, "sdf", 0.1, 60), "pooledstress1024": (640, 480, 1024, "sdf", 0.1, 50), "pooledof512": (640, 480, 512, "ofusion", 0.008, 40)}
+       "ofstress512": (640, 480, 512, "ofusion", 0.008, 60), "pooledstress512": (640, 480, 512, "sdf", 0.1, 60), "pooledstress1024": (640, 480, 1024, "sdf", 0.1, 50), "pooledof512": (640, 480, 512, "ofusion", 0.008, 40)}
 
 
 def frames_of(cfg, n):
