@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the fused raycast + scan launch (profiles/r05af_wave_timeline.md, r05ah_wave_timelines.txt).
+Needs a probe build of the library -- the probe is not part of the product tree:
+    git apply tools/wave_probe.patch && tools/build_variant.sh wlog && git apply -R tools/wave_probe.patch
+    gpurun -- 'SE_HIP_LIB=$PWD/gpurun_ab/wlog.so SE_HIP_WLOG=/tmp/wlog.bin python tools/wave_timeline.py room sdf 512 0.1'
+Lane 0 of every raycast / scan wave writes s_memrealtime (100 MHz) at entry and exit, HW_ID / XCC_ID and the wave maxima of first-leaf trips and march
+batches into a pinned host buffer; the library dumps the buffer of the previous launch when the next one is enqueued.
+usage: wave_timeline.py room|stress sdf|ofusion <volume resolution> <mu>"""
 import sys, os, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, torch
