@@ -1679,7 +1679,7 @@ __device__ __forceinline__ f3 se_grad_lean(const DevMap& m, const FieldConst fc,
 // holds initValue() too).  Returns true if the march is over (t reached tfar).
 // (r05, measured and dropped: 8 / 12 positions per round trip once a run has outlasted the first four -- for the rays past a depth edge on their way to
 // the far wall, ~27 blocks: fused launch 36.2 -> 44.9 / 48.1 us at 512^3, 69.9 -> 88.5 / 90.1 us at 1024^3, although the stand-alone raycast of the
-// same frame is unchanged; profiles/r05al_skip_long_ab.log)
+// same frame is unchanged; the same out of line: 72 us and 32 B of scratch.  profiles/r05al_skip_long_ab.log, r05ap_skip_long2_ab.log)
 template <bool STATS>
 __device__ __forceinline__ bool se_march_skip(const DevMap& m, const RayArgs& a, f3 dir, float tfar, f3& position, float& t, RayCounters& rc) {
 #if SE_MARCH_SKIP > 0
