@@ -10,7 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from supereight_amd.pipeline import DenseSLAMPipeline, SDF  # noqa: E402
+from supereight_amd.pipeline import DenseSLAMPipeline, OFUSION, SDF  # noqa: E402
 from supereight_amd.synthetic import StressStream, to_colmajor  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
@@ -23,11 +23,13 @@ s = StressStream(W, H, 4.8)
 depth = torch.from_numpy(np.stack([s.depth(f) for f in range(PATH)])).cuda()
 poses = [to_colmajor(s.pose(f)) for f in range(PATH)]
 k = np.ascontiguousarray(s.k, np.float32)
-p = DenseSLAMPipeline((W, H), N, 4.8, field_type=SDF, streaming=os.environ.get("SE_SOAK_EAGER") is None)   # the one-queue schedule unless SE_SOAK_EAGER is set
-out = {"workload": f"stress stream {W}x{H} -> {N}^3, {frames} frames (path of {PATH} repeated)", "windows": []}
+OF = os.environ.get("SE_SOAK_FIELD", "sdf") == "ofusion"       # SE_SOAK_FIELD=ofusion: occupancy mapping, mu = 0.02
+MU = 0.02 if OF else 0.1
+p = DenseSLAMPipeline((W, H), N, 4.8, field_type=OFUSION if OF else SDF, streaming=os.environ.get("SE_SOAK_EAGER") is None)   # the one-queue schedule unless SE_SOAK_EAGER is set
+out = {"workload": f"stress stream {W}x{H} -> {N}^3 {'OFusion' if OF else 'SDF'}, {frames} frames (path of {PATH} repeated)", "windows": []}
 t0 = time.perf_counter()
 for f in range(frames):
-    p.frame(depth[f % PATH].data_ptr(), poses[f % PATH], k, 0.1, f)
+    p.frame(depth[f % PATH].data_ptr(), poses[f % PATH], k, MU, f)
     if f % 120 == 119:
         p.sync()
         t1 = time.perf_counter()
