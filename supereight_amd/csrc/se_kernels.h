@@ -32,16 +32,48 @@
 // ------------------------------------------------------------------------------------------
 // index insertion (replaces Octree::allocate / allocate_level, se_core/include/se/octree.hpp:792-856)
 // ------------------------------------------------------------------------------------------
+// Wave-aggregated counters (r06; north-star: "wave-ballot compaction of newly-allocated blocks").  Pool slots and key-list slots are handed out by
+// global counters, and one word takes ~90 atomics per microsecond (se_mark_dilated's note): frame 0 at 2048^3 inserts 402 k blocks, the stress stream
+// 1-3 k per frame at 1024^3.  The lanes of a wave that reach the same insertion point together (`mine` = this lane takes a slot; any divergent context:
+// the ballot sees the lanes that are active here) therefore share ONE atomic: the first of them adds their number, every lane takes base + its rank among
+// them (mbcnt).  Which lane gets which slot was never specified (pool order is the reference's race too, memory_pool.hpp:71); sets are unchanged.
+#ifndef SE_WAVE_AGG
+#define SE_WAVE_AGG 1      // 0: one atomic per lane (the r05 form; A/B: profiles/r06a)
+#endif
+#ifndef SE_DEFER_MARK
+#define SE_DEFER_MARK 1    // 0: beam-start marks in place even when the occupancy bits are deferred (the r05 form); 2: no marks at all (scan bisect; needs SE_HIP_BEAM=0 SE_HIP_OF_LEAP=0)
+#endif
+template <typename T>
+__device__ __forceinline__ T se_wave_take(T* counter, bool mine) {
+  if (!SE_WAVE_AGG) return mine ? atomicAdd(counter, (T)1) : (T)0;
+  const unsigned long long wm = __ballot(mine);
+  if (!mine) return (T)0;
+  const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
+  const int lead = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(wm));
+  T base = (T)0;
+  if (rank == 0u) base = atomicAdd(counter, (T)__builtin_popcountll(wm));
+  if (sizeof(T) == 8) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)base & 0xFFFFFFFFull), lead);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)base >> 32), lead);
+    return (T)((((unsigned long long)hi) << 32) | lo) + (T)rank;
+  }
+  return (T)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, lead) + (T)rank;
+}
+
 // Creates every missing ancestor of the octant (x,y,z)@level.  A thread that loses the CAS
 // stops: the winner keeps walking up, so all ancestors exist when the kernel ends.
-__device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, int x, int y, int z) {
+// `alive`: this lane created the octant (the other lanes of the wave only take part in the shared counter update).
+__device__ __forceinline__ void se_ensure_ancestors(const DevMap& m, int level, int x, int y, int z, bool alive = true) {
   for (int l = level - 1; l >= 1; --l) {
     x >>= 1; y >>= 1; z >>= 1;
     uint32_t* e = m.tab + tab_index(m, l, x, y, z);
-    const uint32_t old = atomicCAS(e, 0u, SE_PENDING);
-    if (old != 0u) break;
-    const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
-    if (nid >= m.cap_nodes) { atomicSub(&m.ctr[C_NODES], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); break; }   // counter stays bounded; reported by the next API call (SE_HIP_E_CAPACITY)
+    bool won = false;
+    if (alive) won = atomicCAS(e, 0u, SE_PENDING) == 0u;
+    alive = won;
+    if (__ballot(won) == 0ull) break;
+    const uint32_t nid = se_wave_take(&m.ctr[C_NODES], won);
+    if (!won) continue;
+    if (nid >= m.cap_nodes) { atomicSub(&m.ctr[C_NODES], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); alive = false; continue; }   // counter stays bounded; reported by the next API call (SE_HIP_E_CAPACITY)
     m.npos[nid] = pack_pos(x, y, z);
     m.nlevel[nid] = (uint8_t)l;
     occ_set(m, l, x, y, z);
@@ -86,36 +118,54 @@ __device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, 
   if (m.fbits) se_mark_dilated(m.fbits, m.leaf_level, bx, by, bz);
 }
 
-__device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int x, int y, int z) {
+// `want` = false: the lane only accompanies the others of its wave (shared counter updates, se_wave_take); the callers pass the lanes that found the
+// entry empty.  A block's beam-start marks (se_mark_coarse) are deferred with its occupancy bits (m.defer_occ: the scan runs beside the previous frame's
+// raycast; se_occ_commit sets both before the next raycast) -- r05 marked in place, up to 18 atomics and a dependent read per new block on the scan's
+// critical path; a block inserted beside a raycast holds initValue() and is invisible to it either way.
+__device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int x, int y, int z, bool want = true) {
   uint32_t* e = m.tab + tab_index(m, level, x, y, z);
-  const uint32_t old = atomicCAS(e, 0u, SE_PENDING);
-  if (old != 0u) return false;
-  if (level == m.leaf_level) {
-    const uint32_t idx = atomicAdd(&m.ctr[C_BLOCKS], 1u);
-    if (idx >= m.cap_blocks) { atomicSub(&m.ctr[C_BLOCKS], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
-    const uint32_t bp = pack_pos(x, y, z);
-    const uint32_t slot = block_slot(m, idx, bp);
-    m.bpos[idx] = bp;
-    m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
-    occ_set(m, level, x, y, z);
-    { const uint32_t lin = block_linear(m, x, y, z); atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u)); }   // (never deferred: a reader that sees the bit early finds PENDING or a brick of initValue())
-    se_mark_coarse(m, x, y, z);   // (never deferred either: an extra bit only makes a raycast's beam start more cautious)
-    atomicExch(e, slot + 1u);
-  } else {
-    const uint32_t nid = atomicAdd(&m.ctr[C_NODES], 1u);
-    if (nid >= m.cap_nodes) { atomicSub(&m.ctr[C_NODES], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); return false; }
-    m.npos[nid] = pack_pos(x, y, z);
-    m.nlevel[nid] = (uint8_t)level;
-    occ_set(m, level, x, y, z);
-    atomicExch(e, nid + 1u);
+  bool won = false;
+  if (want) won = atomicCAS(e, 0u, SE_PENDING) == 0u;
+  if (__ballot(won) == 0ull) return false;
+  const bool leaf = level == m.leaf_level;
+  if (__ballot(won && leaf) != 0ull) {
+    const uint32_t idx = se_wave_take(&m.ctr[C_BLOCKS], won && leaf);
+    if (won && leaf) {
+      if (idx >= m.cap_blocks) { atomicSub(&m.ctr[C_BLOCKS], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); won = false; }
+      else {
+        const uint32_t bp = pack_pos(x, y, z);
+        const uint32_t slot = block_slot(m, idx, bp);
+        m.bpos[idx] = bp;
+        m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
+        occ_set(m, level, x, y, z);
+        { const uint32_t lin = block_linear(m, x, y, z); atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u)); }   // (never deferred: a reader that sees the bit early finds PENDING or a brick of initValue())
+        if (SE_DEFER_MARK == 0 || (SE_DEFER_MARK == 1 && !m.defer_occ)) se_mark_coarse(m, x, y, z);
+        atomicExch(e, slot + 1u);
+      }
+    }
   }
-  se_ensure_ancestors(m, level, x, y, z);
-  return true;
+  if (__ballot(won && !leaf) != 0ull) {
+    const uint32_t nid = se_wave_take(&m.ctr[C_NODES], won && !leaf);
+    if (won && !leaf) {
+      if (nid >= m.cap_nodes) { atomicSub(&m.ctr[C_NODES], 1u); m.ctr[C_OVERFLOW] = 1u; atomicExch(e, 0u); won = false; }
+      else {
+        m.npos[nid] = pack_pos(x, y, z);
+        m.nlevel[nid] = (uint8_t)level;
+        occ_set(m, level, x, y, z);
+        atomicExch(e, nid + 1u);
+      }
+    }
+  }
+  se_ensure_ancestors(m, level, x, y, z, won);
+  return won;
 }
 
 #define SE_KEY_ACTIVATE (1ull << 63)  // list entry = "set VoxelBlock::active_ of this existing block"
-__device__ __forceinline__ void se_append_key(const DevMap& m, int level, int x, int y, int z, unsigned long long flag = 0ull) {
-  const unsigned long long idx = atomicAdd(&m.newkeys[0], 1ull);
+// (`mine` = false: the lane only accompanies its wave, see se_wave_take)
+__device__ __forceinline__ void se_append_key(const DevMap& m, int level, int x, int y, int z, unsigned long long flag = 0ull, bool mine = true) {
+  if (__ballot(mine) == 0ull) return;
+  const unsigned long long idx = se_wave_take(&m.newkeys[0], mine);
+  if (!mine) return;
   if (idx < m.cap_keys) m.newkeys[1 + idx] = se_make_key(x, y, z, level, m.max_level) | flag;
   else m.ctr[C_OVERFLOW] = 2u;
 }
@@ -369,8 +419,9 @@ __global__ __launch_bounds__(SE_WG) void k_alloc_commit(DevMap m, const unsigned
 }
 
 // Deferred occupancy update: when the allocation scan of frame f+1 runs concurrently with the raycast
-// of frame f it inserts into tab[] / the lists but leaves occ[] (which that raycast is walking)
-// alone; this kernel then sets the bits of every inserted octant and of all its ancestors.
+// of frame f it inserts into tab[] / the lists but leaves occ[] (which that raycast is walking) and the
+// beam-start bitmaps cbits / fbits alone; this kernel then sets the bits of every inserted octant and of
+// all its ancestors, and marks the new blocks' neighbourhoods (se_mark_coarse).
 struct OccLists { const unsigned long long* lists; int nlists; long long stride_words; };   // [count, keys...] per list
 // Done by `nwg` workgroups of the launch only, those from index `first` on: every participating thread reads each list's count word first
 // (nlists dependent round trips), which the ~10^4 other waves of a sweep launch need not pay for -- and which workgroup 0 of a sweep, whose
@@ -391,6 +442,7 @@ __device__ __forceinline__ void se_occ_commit(const DevMap& m, const OccLists L,
       const int sh = m.max_level - level;
       int x = (int)(se_compact21(code) >> sh), y = (int)(se_compact21(code >> 1) >> sh), z = (int)(se_compact21(code >> 2) >> sh);
       if ((unsigned)x >= (1u << level) || (unsigned)y >= (1u << level) || (unsigned)z >= (1u << level)) continue;
+      if (SE_DEFER_MARK == 1 && level == m.leaf_level) se_mark_coarse(m, x, y, z);   // the beam-start bitmaps of a deferred insertion (se_insert_octant)
       for (int l = level; l >= 1; --l) {
         const uint32_t c = occ_code(l, x, y, z);
         atomicOr(&m.occ[c >> 5], 1u << (c & 31u));

@@ -65,17 +65,17 @@ def child(cfg, n):
             f += 1
         p.sync()
     p.close()
-    for leg in ("wall", "closed", "events"):
+    for leg in ("wall", "closed", "closed_events", "events"):
         p = DenseSLAMPipeline((W, H), N, 4.8, field_type=fld, **kw)
         for f in range(warm):
             p.frame(ptrs[f], pcm[f], k32, mu, f)
         p.sync()
-        if leg == "events":
+        if leg in ("events", "closed_events"):
             p.enable_timing(True)
         t0 = time.perf_counter()
         for f in range(warm, n):
             p.frame(ptrs[f], pcm[f], k32, mu, f)
-            if leg == "closed":
+            if leg in ("closed", "closed_events"):
                 p.sync()
         p.sync()
         dt = time.perf_counter() - t0
@@ -84,6 +84,10 @@ def child(cfg, n):
             out["us_per_frame"] = round(1e6 * dt / (n - warm), 2)
         elif leg == "closed":
             out["closed_loop_fps"] = round((n - warm) / dt, 1)
+        elif leg == "closed_events":   # one sync per frame: every launch is a stand-alone kernel in the cache state the pipeline leaves (r06)
+            tm = p.timings(reset=True)
+            p.enable_timing(False)
+            out["closed_kernels_us"] = {kk: round(1e3 * v["ms_sum"] / v["launches"], 2) for kk, v in tm.items() if v["launches"]}
         else:
             tm = p.timings(reset=True)
             p.enable_timing(False)
@@ -142,5 +146,5 @@ if __name__ == "__main__":
                 continue
             d = json.loads(line[-1])
             ref = ref or d["sha1"]
-            print(f"{cfg:>10} {name:>14}: {d['fps']:>8} fps ({d['us_per_frame']} us)  closed {d['closed_loop_fps']:>8}  kernels {d['kernels_us']}  raycast alone {d['raycast_alone_us']}  "
+            print(f"{cfg:>10} {name:>14}: {d['fps']:>8} fps ({d['us_per_frame']} us)  closed {d['closed_loop_fps']:>8} {d.get('closed_kernels_us')}  kernels {d['kernels_us']}  raycast alone {d['raycast_alone_us']}  "
                   f"blocks {d['blocks']}  sha1 {d['sha1']} {'SAME' if d['sha1'] == ref else 'DIFFERENT'}", flush=True)
