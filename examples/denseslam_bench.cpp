@@ -11,7 +11,11 @@
 //              depth handed over in HBM (preprocessingDevice);
 //   streaming  frames issued back to back, one synchroniseDevices() at the end (poses known in advance); raycasting() of frame f is held back
 //              and launched with integration(f+1)'s allocation scan -- the one-queue schedule (Configuration::hip_streaming);
-//   upload     as `closed`, but every frame's depth comes from host memory as uint16 millimetres through preprocessing(): the PCIe-inclusive rate.
+//   upload     as `closed`, but every frame's depth comes from host memory as uint16 millimetres through preprocessing(): the PCIe-inclusive rate;
+//   streaming + upload   as `streaming` with that host input: what the reference's own loop (read a frame, preprocessing, ..., benchmark.cpp:115-150) gets
+//              when its poses do not depend on the previous frame's images -- the input of frame f+1 crosses PCIe inside the launch that raycasts frame f;
+//   tracked    the reference's loop with tracking on (preprocessing -> tracking -> integration -> raycasting, nothing else between the frames), host input:
+//              tracking(f+1) needs raycasting(f)'s images, so the class launches raycasts eagerly after the first frames (se_hip.h, streaming callers).
 // Prints one JSON line; the per-frame log of the closed pass goes to log.tsv.
 #ifndef SE_FIELD_TYPE
 #define SE_FIELD_TYPE SDF
@@ -70,13 +74,14 @@ Configuration make_config(int res, float dim, float mu, const float k[4], bool s
   return c;
 }
 
-struct Pass { double fps = 0, integration_ms = 0, raycasting_ms = 0, preprocessing_ms = 0; int blocks = 0; };
+struct Pass { double fps = 0, integration_ms = 0, raycasting_ms = 0, preprocessing_ms = 0, tracking_ms = 0; int blocks = 0; };
 
-enum Mode { CLOSED, STREAMING, UPLOAD };
+enum Mode { CLOSED, STREAMING, UPLOAD, STREAMING_UPLOAD, TRACKED };
 
 Pass run(const Stream& s, int res, float dim, float mu, int warm, int frames, Mode mode, FILE* log) {
   std::vector<int> pyramid = {10, 5, 4};
-  const Configuration config = make_config(res, dim, mu, s.k, mode == STREAMING);
+  const bool stream_mode = mode == STREAMING || mode == STREAMING_UPLOAD;
+  const Configuration config = make_config(res, dim, mu, s.k, mode != CLOSED && mode != UPLOAD);
   DenseSLAMSystem pipeline(Eigen::Vector2i(s.W, s.H), config.volume_resolution, config.volume_size, Eigen::Vector3f(0.f, 0.f, 0.f), pyramid, config);
   const Eigen::Vector4f camera(s.k[0], s.k[1], s.k[2], s.k[3]);
   const size_t n = (size_t)s.W * s.H;
@@ -87,19 +92,22 @@ Pass run(const Stream& s, int res, float dim, float mu, int warm, int frames, Mo
   for (int frame = 0; frame < warm + frames; ++frame) {
     if (frame == warm) { synchroniseDevices(); t_begin = Clock::now(); timings[0] = t_begin; }
     timings[1] = Clock::now();
-    if (mode == UPLOAD) pipeline.preprocessing(&s.depth_mm[n * frame], Eigen::Vector2i(s.W, s.H), false);
+    if (mode == UPLOAD || mode == STREAMING_UPLOAD || mode == TRACKED) pipeline.preprocessing(&s.depth_mm[n * frame], Eigen::Vector2i(s.W, s.H), false);
     else pipeline.preprocessingDevice(s.dev + n * frame);
     timings[2] = Clock::now();
-    pipeline.setPose(s.pose[frame]);              // ground truth in place of tracking() (se_apps/src/mainQt.cpp:257-265 does the same)
+    bool tracked = true;
+    if (mode == TRACKED && frame > 3) tracked = pipeline.tracking(camera, config.icp_threshold, config.tracking_rate, (unsigned)frame);
+    else pipeline.setPose(s.pose[frame]);         // ground truth in place of tracking() (se_apps/src/mainQt.cpp:257-265 does the same)
     timings[3] = Clock::now();
-    const bool integrated = pipeline.integration(camera, config.integration_rate, config.mu, (unsigned)frame);
+    const bool integrated = (tracked || frame <= 3) ? pipeline.integration(camera, config.integration_rate, config.mu, (unsigned)frame) : false;   // benchmark.cpp:137-147
     timings[4] = Clock::now();
     pipeline.raycasting(camera, config.mu, (unsigned)frame);
-    if (mode != STREAMING) synchroniseDevices();  // the reference's kernels are synchronous: its raycasting column ends when the images exist
+    if (!stream_mode && mode != TRACKED) synchroniseDevices();  // the reference's kernels are synchronous: its raycasting column ends when the images exist
     timings[5] = Clock::now();
     timings[6] = timings[5];                      // (no rendering in the measured loop)
     if (frame >= warm) {
       out.preprocessing_ms += 1e3 * secs(timings[1], timings[2]);
+      out.tracking_ms += 1e3 * secs(timings[2], timings[3]);
       out.integration_ms += 1e3 * secs(timings[3], timings[4]);
       out.raycasting_ms += 1e3 * secs(timings[4], timings[5]);
     }
@@ -114,7 +122,7 @@ Pass run(const Stream& s, int res, float dim, float mu, int warm, int frames, Mo
   synchroniseDevices();
   const double total = secs(t_begin, Clock::now());
   out.fps = frames / total;
-  out.preprocessing_ms /= frames; out.integration_ms /= frames; out.raycasting_ms /= frames;
+  out.preprocessing_ms /= frames; out.integration_ms /= frames; out.raycasting_ms /= frames; out.tracking_ms /= frames;
   MapSnapshot snap;
   int nb = 0, nn = 0;
   se_hip_counts(pipeline.handle(), &nb, &nn);
@@ -137,14 +145,19 @@ int main(int argc, char** argv) {
   const Pass closed = run(s, res, dim, mu, warm, frames, CLOSED, log);
   const Pass streaming = run(s, res, dim, mu, warm, frames, STREAMING, nullptr);
   const Pass upload = run(s, res, dim, mu, warm, frames, UPLOAD, nullptr);
+  const Pass stream_up = run(s, res, dim, mu, warm, frames, STREAMING_UPLOAD, nullptr);
+  const Pass tracked = run(s, res, dim, mu, warm, frames, TRACKED, nullptr);
   if (log) std::fclose(log);
   std::printf("{\"surface\": \"DenseSLAMSystem (include/se/DenseSLAMSystem.h) over libse_hip.so\", \"frames\": %d, \"warmup\": %d, \"blocks\": %d, "
               "\"closed_loop_fps\": %.1f, \"closed_loop_stage_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
               "\"streaming_fps\": %.1f, \"streaming_enqueue_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
-              "\"closed_loop_fps_with_upload\": %.1f, \"upload_stage_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}}\n",
+              "\"closed_loop_fps_with_upload\": %.1f, \"upload_stage_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
+              "\"streaming_fps_with_upload\": %.1f, \"streaming_upload_enqueue_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
+              "\"tracked_fps_with_upload\": %.1f, \"tracked_stage_ms\": {\"preprocessing\": %.4f, \"tracking\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}}\n",
               frames, warm, closed.blocks, closed.fps, closed.preprocessing_ms, closed.integration_ms, closed.raycasting_ms, streaming.fps,
               streaming.preprocessing_ms, streaming.integration_ms, streaming.raycasting_ms, upload.fps, upload.preprocessing_ms, upload.integration_ms,
-              upload.raycasting_ms);
+              upload.raycasting_ms, stream_up.fps, stream_up.preprocessing_ms, stream_up.integration_ms, stream_up.raycasting_ms,
+              tracked.fps, tracked.preprocessing_ms, tracked.tracking_ms, tracked.integration_ms, tracked.raycasting_ms);
   hipFree(s.dev);
   return 0;
 }

@@ -54,6 +54,7 @@ struct DevMap {
                                   // 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 (second stage of the beam start); null if leaf_level <= clevel
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
+  int defer_mark;                 // 1: insertions do not mark cbits / fbits (se_occ_commit does, from the key list, before the next raycast: every allocation scan)
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
   uint32_t leaf_off;              // = off[leaf_level]; kept separately so that hot kernels never index off[] dynamically
   float dim;

@@ -115,13 +115,17 @@ struct se_hip_pipeline {
   // the sweep.  Any other API call launches the deferred raycast first (check()), so results are always in place when somebody looks through the API;
   // a caller that was handed the raw image pointers (se_hip_vertex_normal_device, no image ring) could look past the API: that switches deferral off for good.
   bool fuse = false, in_frame = false, has_pending = false;
+  // A held-back raycast that some other call has to launch (se_hip_track needs vertex_ / normal_, a getter, a per-frame se_hip_sync) was held back for
+  // nothing: it starts later than the eager schedule would have started it and fuses with no scan (the reference's loop with tracking on).
+  // Two such launches in a row without a fused one in between -> this caller looks at every frame: raycasts are launched eagerly from then on
+  // (se_hip_set_streaming(p, 1) arms deferral again).
+  int flush_streak = 0;
   bool ptrs_exposed = false;   // sticky: se_hip_vertex_normal_device handed out vertex_ / normal_ of a handle without an image ring
   float pend_pose[16] = {0}, pend_k[4] = {0}, pend_mu = 0.f;
   uint32_t pend_frame = 0;
   bool images_complete = true; // vertex_ / normal_ hold every row of the last raycast (a row-sharded replica: only after se_hip_apply_image_tiles / se_hip_gather_images)
   bool scan_pending = false;   // a scan was enqueued on `side` and not yet joined by `stream`
   bool scan_on_side = false;   // stream the LAST allocation scan ran on: se_hip_alloc_exchange / se_hip_alloc_commit follow it
-  bool upload_on_side = false; // the current depth image was uploaded on `side`
   const float* scaled0 = nullptr;   // scaled_depth_[0] of the last se_hip_track
   // direct RCCL exchange of the key lists (se_hip_set_exchange): the caller's communicator and ncclAllGather
   void* xcomm = nullptr;
@@ -157,19 +161,24 @@ struct se_hip_pipeline {
   size_t slots = 0;
   size_t cap_blocks = 0, cap_nodes = 0;
   int ray_cache_levels = -1;  // -1: choose automatically
-  float* depth_own = nullptr;       // width*height floats
-  const float* depth = nullptr;     // what the kernels read (own buffer or caller's)
-  unsigned short* depth_mm = nullptr;
-  size_t depth_mm_cap = 0;
-  // host depth images are copied into a ring of pinned buffers and DMA'd from there: the call returns as
-  // soon as the caller's buffer has been read (the reference's preprocessing() is synchronous), the
-  // transfer itself is asynchronous (a pageable hipMemcpyAsync of < 1 MB blocks on the stream instead)
-  static constexpr int kStage = 3;
-  void* stage_host[kStage] = {nullptr, nullptr, nullptr};
-  hipEvent_t stage_done[kStage] = {nullptr, nullptr, nullptr};
-  bool stage_used[kStage] = {false, false, false};
-  size_t stage_cap = 0;
-  int stage_next = 0;
+  const float* depth = nullptr;     // what the kernels read: a slot of the handle's own ring or the caller's device image (se_hip_set_depth_device)
+  // Host input (se_hip_upload_depth / se_hip_upload_depth_mm; r06): the caller's image is copied into a slot of a ring of pinned host buffers -- the call
+  // returns when the caller's buffer has been read, as the reference's synchronous preprocessing() does -- and NOTHING is enqueued: the first kernel that
+  // needs float_depth_ reads the pinned image over PCIe and writes the matching slot of the device ring (DepthSrc, se_kernels.h): the frame's allocation
+  // scan, or k_depth_from_host in front of a consumer that comes earlier (tracking, renderDepth, a row-sharded scan).  No DMA packet, no second queue,
+  // no wait for the previous sweep: slot i is reused kIn uploads later, once a raycast enqueued behind the last sweep that read it has started (the
+  // host gate's sequence word; without a host gate: an event recorded behind that sweep).
+  static constexpr int kIn = 3;
+  float* depth_ring[kIn] = {nullptr, nullptr, nullptr};   // device, width*height floats each
+  void* in_host[kIn] = {nullptr, nullptr, nullptr};       // pinned
+  size_t in_cap = 0;
+  int in_next = 0;
+  int in_state[kIn] = {0, 0, 0};            // 0 free, 1 read by enqueued work that no raycast launch has followed yet, 2 followed: reusable once gate_host reaches in_seq
+  uint32_t in_seq[kIn] = {0, 0, 0};
+  hipEvent_t in_done[kIn] = {nullptr, nullptr, nullptr};   // handles without a host gate
+  bool in_event[kIn] = {false, false, false};
+  int cur_in = -1;                          // ring slot p->depth points into (-1: the caller's device image)
+  DepthSrc in_pending{nullptr, nullptr, 0, 0, 0};   // host-resident input not yet materialised on the device
   float* vertex = nullptr;       // vertex_ / normal_ as every consumer (tracking, rendering, the getters) sees them: the images of the LAST raycast
   float* normal = nullptr;       // launched -- the handle's own buffers, or the slot of the image ring that raycast wrote
   float* vertex_own = nullptr;
@@ -339,6 +348,17 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.leap_bits = !p->of_leap ? nullptr : m.fbits ? m.fbits : (m.clevel == m.leaf_level ? m.cbits : nullptr);
   a.leap_level = m.leaf_level;
   a.leap_dt = 0.9f * a.beam_cellf;
+  a.wlog = nullptr;
+#ifdef SE_WAVE_PROBE
+  {
+    // probe builds (tools/wave_timeline.py): the per-wave records of the PREVIOUS raycast launch are written to $SE_HIP_WLOG when the next one is prepared
+    static unsigned long long* wl = nullptr;
+    static bool tried = false;
+    if (!tried) { tried = true; if (std::getenv("SE_HIP_WLOG")) { hipHostMalloc((void**)&wl, 4 * 8 * 32768, 0); std::memset(wl, 0, 4 * 8 * 32768); } }
+    a.wlog = wl;
+    if (wl) { hipStreamSynchronize(p->stream); if (FILE* f = std::fopen(std::getenv("SE_HIP_WLOG"), "wb")) { std::fwrite(wl, 8, 4 * 32768, f); std::fclose(f); } std::memset(wl, 0, 4 * 8 * 32768); }
+  }
+#endif
   L.smem = ((size_t)a.cache_words + (size_t)2 * a.stack_depth * SE_WG_RAY) * sizeof(uint32_t);
   const int tiles_x = (a.W + SE_TILE_W - 1) / SE_TILE_W, tiles_y = (a.row_end - a.row_begin + SE_TILE_H - 1) / SE_TILE_H;
   // one workgroup per tile pair, in whole rounds over the compute units (workgroups of the last round beyond the list idle)
@@ -364,13 +384,19 @@ void wait_last_sweep(se_hip_pipeline* p) {
   hipStreamSynchronize(p->stream);
 }
 
-// Overlap mode: depth uploads go to the side stream, behind the previous sweep (the last reader of
-// the depth buffer) and in front of the scan that consumes them.
-hipStream_t upload_stream(se_hip_pipeline* p) {
-  if (!p->overlap) return p->stream;
-  if (p->host_gate) wait_last_sweep(p);
-  else hipStreamWaitEvent(p->side, p->ev_sweep, 0);
-  return p->side;
+// float_depth_ on the device for a consumer on stream `s` that is not the frame's allocation scan: a host-resident input is converted / copied by
+// one kernel in stream order (reads the pinned image over PCIe)
+void materialise_depth(se_hip_pipeline* p, hipStream_t s) {
+  if (p->in_pending.kind == 0) return;
+  const int W = p->cfg.width, H = p->cfg.height;
+  hipLaunchKernelGGL(k_depth_from_host, dim3((W + 255) / 256, H), dim3(256), 0, s, p->in_pending, W, H);
+  p->in_pending.kind = 0;
+}
+// enqueued work reads the current input slot (a scan, a sweep, the tracker's pyramid): it may not be overwritten before that work is done
+void input_slot_in_use(se_hip_pipeline* p) { if (p->cur_in >= 0) { p->in_state[p->cur_in] = 1; p->in_event[p->cur_in] = false; } }
+// a raycast launch with gate sequence `seq` was enqueued: once it has started, everything enqueued before it on the main stream is done
+void input_slots_followed(se_hip_pipeline* p, uint32_t seq) {
+  for (int i = 0; i < se_hip_pipeline::kIn; ++i) if (p->in_state[i] == 1) { p->in_state[i] = 2; p->in_seq[i] = seq; }
 }
 
 // Makes the main stream see a scan that ran on the side stream: wait for it, then publish the
@@ -379,15 +405,12 @@ hipStream_t upload_stream(se_hip_pipeline* p) {
 int join_scan(se_hip_pipeline* p, bool fold_into_sweep = false) {
   if (p->scan_pending) {
     p->scan_pending = false;
-    p->upload_on_side = false;
     HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_scan, 0));
     p->occ_commit_due = true;
     if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
     // keys[0] quirk: a row-sharded replica applies it in se_hip_alloc_commit, over every rank's list
     if (p->cfg.field_type == SE_HIP_FIELD_OFUSION && !p->sharded)
       if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r;
-  } else if (p->upload_on_side) {
-    hipEventRecord(p->ev_scan, p->side); hipStreamWaitEvent(p->stream, p->ev_scan, 0); p->upload_on_side = false;
   }
   // the sweep kernel publishes the bits itself when it is the next launch (fold_into_sweep)
   if (p->occ_commit_due && !fold_into_sweep) {
@@ -406,7 +429,7 @@ int check(se_hip_pipeline* p) {
     hipError_t e = hipSetDevice(p->device);
     if (e != hipSuccess) return fail(SE_HIP_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
   }
-  if (p->has_pending && !p->in_frame) return flush_pending_raycast(p);   // whoever calls anything but se_hip_frame gets the deferred raycast first
+  if (p->has_pending && !p->in_frame) { ++p->flush_streak; return flush_pending_raycast(p); }   // whoever calls anything but se_hip_frame gets the deferred raycast first
   return SE_HIP_OK;
 }
 
@@ -599,7 +622,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(m.newkeys, (m.cap_keys + 1) * sizeof(unsigned long long));
   p->newkeys_own = m.newkeys; p->cap_keys_own = m.cap_keys;
   ALLOC(p->newkeys_own2, (m.cap_keys + 1) * sizeof(unsigned long long));
-  ALLOC(p->depth_own, (size_t)cfg->width * cfg->height * sizeof(float));
+  for (int i = 0; i < se_hip_pipeline::kIn; ++i) ALLOC(p->depth_ring[i], (size_t)cfg->width * cfg->height * sizeof(float));
   ALLOC(p->vertex_own, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   ALLOC(p->normal_own, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   p->vertex = p->vertex_own; p->normal = p->normal_own;
@@ -620,14 +643,14 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
     hipStreamSynchronize(p->stream);   // (the host vector goes out of scope)
   }
   { const int off[4] = {256, 256, 256, 0}; hipMemcpyAsync(p->prio_thr, off, sizeof off, hipMemcpyHostToDevice, p->stream); }
-  p->depth = p->depth_own;
+  p->depth = p->depth_ring[0]; p->cur_in = 0;
   e = hipHostMalloc((void**)&p->ctr_host, C_COUNT * sizeof(uint32_t));
   if (e != hipSuccess) return bail(e, "hipHostMalloc");
   std::memset(p->ctr_host, 0, C_COUNT * sizeof(uint32_t));
 
   p->cap_blocks = cap; p->cap_nodes = capn;
   reset_map_state(p);
-  hipMemsetAsync(p->depth_own, 0, (size_t)cfg->width * cfg->height * sizeof(float), p->stream);
+  for (int i = 0; i < se_hip_pipeline::kIn; ++i) hipMemsetAsync(p->depth_ring[i], 0, (size_t)cfg->width * cfg->height * sizeof(float), p->stream);
   hipMemsetAsync(p->vertex, 0, (size_t)cfg->width * cfg->height * 3 * sizeof(float), p->stream);
   hipMemsetAsync(p->normal, 0, (size_t)cfg->width * cfg->height * 3 * sizeof(float), p->stream);
   if (cfg->field_type == SE_HIP_FIELD_OFUSION) {
@@ -656,7 +679,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
   void* ptrs[] = {m.occ, m.lbits, m.cbits, m.fbits, m.tab, m.vx, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
-                  p->depth_own, p->depth_mm, p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
+                  p->depth_ring[0], p->depth_ring[1], p->depth_ring[2], p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
   for (auto* q : p->pyr_vertex) if (q) hipFree(q);
@@ -669,7 +692,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   if (p->ctr_host) hipHostFree(p->ctr_host);
   if (p->gate_host) hipHostFree(p->gate_host);
   if (p->mesh_ctr) hipFree(p->mesh_ctr);
-  for (int i = 0; i < se_hip_pipeline::kStage; ++i) { if (p->stage_host[i]) hipHostFree(p->stage_host[i]); if (p->stage_done[i]) hipEventDestroy(p->stage_done[i]); }
+  for (int i = 0; i < se_hip_pipeline::kIn; ++i) { if (p->in_host[i]) hipHostFree(p->in_host[i]); if (p->in_done[i]) hipEventDestroy(p->in_done[i]); }
   if (p->own_side && p->side) hipStreamDestroy(p->side);
   if (p->ev_sweep) hipEventDestroy(p->ev_sweep);
   if (p->ev_scan) hipEventDestroy(p->ev_scan);
@@ -730,31 +753,37 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
   return SE_HIP_OK;
 }
 
-// host -> device through the pinned staging ring (see se_hip_pipeline::stage_host)
-int staged_upload(se_hip_pipeline* p, void* dev, const void* host, size_t bytes, hipStream_t s) {
-  // measured on MI355X / ROCm 7.2 (r02 measurement): from 1 MB up the runtime's own pageable path (it pins
-  // the pages and DMAs from them) beats a host-side copy into the ring; below that it blocks on the stream
-  if (bytes >= ((size_t)1 << 20)) { HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s)); return SE_HIP_OK; }
-  if (p->stage_cap < bytes) {
-    for (int i = 0; i < se_hip_pipeline::kStage; ++i) {
-      if (p->stage_used[i]) hipEventSynchronize(p->stage_done[i]);
-      if (p->stage_host[i]) hipHostFree(p->stage_host[i]);
-      p->stage_host[i] = nullptr; p->stage_used[i] = false;
-    }
-    p->stage_cap = 0;
-    for (int i = 0; i < se_hip_pipeline::kStage; ++i) {
-      HIP_TRY(hipHostMalloc(&p->stage_host[i], bytes));
-      if (!p->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->stage_done[i], hipEventDisableTiming));
-    }
-    p->stage_cap = bytes;
+// Host image -> the next slot of the pinned input ring (see se_hip_pipeline::in_host); nothing is enqueued.
+static int stage_input(se_hip_pipeline* p, const void* host, size_t bytes, int kind, int in_w, int ratio) {
+  constexpr int R = se_hip_pipeline::kIn;
+  if (p->in_cap < bytes) {
+    // (first call, or a larger input image: the slots' pending readers first)
+    if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < R; ++i) { if (p->in_host[i]) hipHostFree(p->in_host[i]); p->in_host[i] = nullptr; p->in_state[i] = 0; p->in_event[i] = false; }
+    p->in_cap = 0; p->in_pending.kind = 0;
+    for (int i = 0; i < R; ++i) HIP_TRY(hipHostMalloc(&p->in_host[i], bytes));
+    p->in_cap = bytes;
   }
-  const int i = p->stage_next;
-  p->stage_next = (i + 1) % se_hip_pipeline::kStage;
-  if (p->stage_used[i]) HIP_TRY(hipEventSynchronize(p->stage_done[i]));   // three uploads ago: long finished
-  std::memcpy(p->stage_host[i], host, bytes);
-  HIP_TRY(hipMemcpyAsync(dev, p->stage_host[i], bytes, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipEventRecord(p->stage_done[i], s));
-  p->stage_used[i] = true;
+  const int i = p->in_next;
+  p->in_next = (i + 1) % R;
+  // the slot's last readers (three uploads ago) must be done: normally long true
+  if (p->in_state[i] == 2 && p->host_gate) {
+    volatile uint32_t* w = p->gate_host;
+    const uint32_t target = p->in_seq[i];
+    if (!spin_until([&] { return (int32_t)(*w - target) >= 0; }, 20000)) { if (p->side) hipStreamSynchronize(p->side); hipStreamSynchronize(p->stream); }
+  } else if (p->in_event[i]) {
+    HIP_TRY(hipEventSynchronize(p->in_done[i]));
+  } else if (p->in_state[i] != 0) {
+    // read by enqueued work that nothing has followed yet (integration-only callers, three uploads without a raycast)
+    if (p->side) HIP_TRY(hipStreamSynchronize(p->side));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  p->in_state[i] = 0; p->in_event[i] = false;
+  std::memcpy(p->in_host[i], host, bytes);
+  p->in_pending = DepthSrc{p->in_host[i], p->depth_ring[i], kind, in_w, ratio};
+  p->depth = p->depth_ring[i];
+  p->cur_in = i;
   return SE_HIP_OK;
 }
 
@@ -763,11 +792,7 @@ int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m) {
   InFrame guard(p);   // (a deferred raycast reads the map, not the depth image: the next frame's input may arrive before it is launched)
   if (int r = check(p)) return r;
   if (!host_depth_m) return fail(SE_HIP_E_INVALID, "null depth");
-  hipStream_t s = upload_stream(p);
-  if (int r = staged_upload(p, p->depth_own, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), s)) return r;
-  if (!p->overlap) {} else p->upload_on_side = true;
-  p->depth = p->depth_own;
-  return SE_HIP_OK;
+  return stage_input(p, host_depth_m, (size_t)p->cfg.width * p->cfg.height * sizeof(float), 2, p->cfg.width, 1);
 }
 
 int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t in_w, int32_t in_h) {
@@ -778,56 +803,43 @@ int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t 
   const int W = p->cfg.width, H = p->cfg.height;
   // the reference prints "Invalid ratio." and exits (preprocessing.cpp:165-176); here it is an error code
   if (in_w < W || in_h < H || in_w % W != 0 || in_h % H != 0 || in_w / W != in_h / H) return fail(SE_HIP_E_INVALID, "Invalid ratio.");
-  const size_t n = (size_t)in_w * in_h;
-  if (p->depth_mm_cap < n) {
-    if (p->depth_mm) hipFree(p->depth_mm);
-    p->depth_mm = nullptr; p->depth_mm_cap = 0;
-    HIP_TRY(hipMalloc((void**)&p->depth_mm, n * sizeof(unsigned short)));
-    p->depth_mm_cap = n;
-  }
-  hipStream_t s = upload_stream(p);
-  if (int r = staged_upload(p, p->depth_mm, host_mm, n * sizeof(unsigned short), s)) return r;
-  hipLaunchKernelGGL(k_mm2meters, dim3((W + 255) / 256, H), dim3(256), 0, s, p->depth_own, W, H, p->depth_mm, in_w, in_w / W);
-  if (p->overlap) p->upload_on_side = true;
-  HIP_TRY(hipGetLastError());
-  p->depth = p->depth_own;
-  return SE_HIP_OK;
+  return stage_input(p, host_mm, (size_t)in_w * in_h * sizeof(unsigned short), 1, in_w, in_w / W);   // mm2metersKernel happens where the image is first read
 }
 
 int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");
   InFrame guard(p);
   if (int r = check(p)) return r;
-  p->depth = device_depth_m ? device_depth_m : p->depth_own;
+  if (device_depth_m) { p->depth = device_depth_m; p->cur_in = -1; p->in_pending.kind = 0; }   // (an upload not yet consumed is dropped: the caller replaced the input)
+  else if (p->cur_in < 0) { p->depth = p->depth_ring[0]; p->cur_in = 0; }
   return SE_HIP_OK;
 }
 
 // The deferred raycast of the previous se_hip_frame call + this frame's allocation scan as one launch on the main stream (k_raycast_scan).
-int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& sa, int scan_wgs) {
+int launch_raycast_scan(se_hip_pipeline* p, const DevMap& ms, const AllocArgs& sa, int scan_wgs, const DepthSrc& ds) {
   const DevMap& m = p->map;
-  p->has_pending = false;
+  // (an overflow reported here must not drop the held-back raycast -- se_hip_frame(f) has already said "raycast ran": it stays pending and is
+  // launched by the first call after se_hip_clear_overflow)
   if (int r = check_overflow(p)) return r;
+  p->has_pending = false;
+  p->flush_streak = 0;
   std::memcpy(p->raycast_pose, p->pend_pose, sizeof p->raycast_pose);   // raycast_pose_ = pose_ (DenseSLAMSystem.cpp:196)
   p->images_complete = !p->sharded;
   select_image_target(p, p->pend_frame);
   p->n_launch[SE_HIP_K_ALLOC_SCAN]++; p->n_launch[SE_HIP_K_COUNT]++;   // (the raycast half is counted by the timer scope below)
   RayLaunchArgs L = make_ray_args(p, p->pend_pose, p->pend_k, p->pend_mu);
-  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
+  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; input_slots_followed(p, L.a.gate_seq); }
   const RayArgs& a = L.a;
   const int ray_wgs = (int)L.grid.x;
   const size_t smem = std::max(L.smem, (size_t)SE_SCAN_SLOTS * SE_WG_SCAN * sizeof(uint32_t));
   const dim3 grid((unsigned)(ray_wgs + scan_wgs)), block(SE_WG_RAY);
-  // workgroups of 2 waves the chip holds at once at 5 waves per SIMD (k_raycast_scan): the raycast's workgroups all start at once, the scan's follow.
-  // (r05, measured: letting scan workgroups in earlier -- the first 1 280 / 640 / 0 workgroups the raycast's, then alternating -- delays raycast waves and
-  // the launch ends later by 1 / 3 / 8 us at 512^3 SDF and 16 / 25 / 31 us for OFusion, profiles/r05p_fuse_first_ab.log)
-  const int first_round = 10 * p->n_cus;
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
   const size_t nb = (size_t)(m.size >> 3);
   // (a dense grid of > 4 GiB with every level staged -- only with SE_HIP_RAY_CACHE_LEVELS raised -- takes the generic instantiation)
   const bool shallow = !a.has_deep && !(m.dense && nb * nb * nb * (size_t)SE_BRICK_STRIDE * sizeof(float) > ((size_t)4 << 30));
   {
     ScopedTimer t(p, SE_HIP_K_RAYCAST);
-#define SE_RS(OF, DN, SH, O3) hipLaunchKernelGGL((k_raycast_scan<OF, DN, SH, O3>), grid, block, smem, p->stream, m, a, p->vertex, p->normal, ray_wgs, ms, p->depth, sa, scan_wgs, first_round)
+#define SE_RS(OF, DN, SH, O3) hipLaunchKernelGGL((k_raycast_scan<OF, DN, SH, O3>), grid, block, smem, p->stream, m, a, p->vertex, p->normal, ray_wgs, ms, p->depth, sa, ds)
     if (sdf) {
       if (m.dense) { if (shallow) SE_RS(false, true, true, true); else SE_RS(false, true, false, false); }
       else { if (shallow) SE_RS(false, false, true, false); else SE_RS(false, false, false, false); }
@@ -890,6 +902,7 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   hipStream_t s = ov ? p->side : p->stream;
   DevMap ms = m;
   ms.defer_occ = (ov || fuse_now) ? 1 : 0;
+  ms.defer_mark = 1;   // the beam-start bitmaps of the new blocks are set from the key list by the sweep in front of the next raycast (se_occ_commit), whatever the schedule
   if (ov) { if (p->host_gate) wait_last_sweep(p); else HIP_TRY(hipStreamWaitEvent(p->side, p->ev_sweep, 0)); }
   else if (p->overlap) { if (int r = join_scan(p)) return r; }   // a depth upload that went to the scan stream is joined here
   const bool own_list = p->map.newkeys == p->newkeys_own || p->map.newkeys == p->newkeys_own2;
@@ -906,15 +919,22 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   }
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
   const dim3 grid((npix + SE_WG_SCAN - 1) / SE_WG_SCAN), block(SE_WG_SCAN);
+  // an input image still in host memory: this scan visits every pixel once and materialises float_depth_ on its way (DepthSrc); a row-sharded replica's
+  // scan sees only its own rows, the sweep behind it needs all of them
+  if (a.sharded) materialise_depth(p, s);
+  const DepthSrc ds = p->in_pending;
+  p->in_pending.kind = 0;
+  // SDF: a wave = an 8x8 pixel tile, or 64 pixels of a row when it reads the image from host memory (se_scan_sdf_wg)
+  const int sdf_tiles = ds.kind ? ((p->cfg.width + 63) / 64) * (p->row_end - p->row_begin) : ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
   if (!sdf) {
     // the three stages' levels (fetch_octant stops at the leaves) and their offsets in the index pyramid (tiled kernel)
     const int dep[3] = {a.depth_fine, a.depth_mid, a.depth_coarse};
     for (int i = 0; i < 3; ++i) { a.of_lvl[i] = std::min(dep[i], m.leaf_level); a.of_off[i] = a.of_lvl[i] >= 1 ? m.off[a.of_lvl[i]] : 0u; }
   }
   if (fuse_now) {
-    const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);
-    const int scan_wgs = sdf ? (tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64) : (int)grid.x;
-    if (int r = launch_raycast_scan(p, ms, a, scan_wgs)) return r;
+    const int scan_wgs = sdf ? (sdf_tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64) : (int)grid.x;
+    if (int r = launch_raycast_scan(p, ms, a, scan_wgs, ds)) return r;
+    input_slot_in_use(p);
     p->occ_commit_due = true;
     if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
     if (!sdf && !a.sharded) { if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r; }   // (sharded: se_hip_alloc_commit, over every rank's list)
@@ -924,26 +944,29 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   {
     ScopedTimer t(p, SE_HIP_K_ALLOC_SCAN, s);
     if (sdf) {
-      const int tiles = ((p->cfg.width + 7) / 8) * ((p->row_end - p->row_begin + 7) / 8);   // a wave = an 8x8 pixel tile
-      const dim3 sgrid((tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
+      const dim3 sgrid((sdf_tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64));
       if (m.dense) {
-        if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, true>), sgrid, block, 0, s, ms, p->depth, a);
-        else hipLaunchKernelGGL((k_alloc_scan_sdf<false, true>), sgrid, block, 0, s, ms, p->depth, a);
+        if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, true>), sgrid, block, 0, s, ms, p->depth, a, ds);
+        else hipLaunchKernelGGL((k_alloc_scan_sdf<false, true>), sgrid, block, 0, s, ms, p->depth, a, ds);
       } else {
-        if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, false>), sgrid, block, 0, s, ms, p->depth, a);
-        else hipLaunchKernelGGL((k_alloc_scan_sdf<false, false>), sgrid, block, 0, s, ms, p->depth, a);
+        if (p->stats) hipLaunchKernelGGL((k_alloc_scan_sdf<true, false>), sgrid, block, 0, s, ms, p->depth, a, ds);
+        else hipLaunchKernelGGL((k_alloc_scan_sdf<false, false>), sgrid, block, 0, s, ms, p->depth, a, ds);
       }
     } else {
-      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a);
-      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a);
+      if (p->stats) hipLaunchKernelGGL(k_alloc_scan_ofusion<true>, grid, block, 0, s, ms, p->depth, a, ds);
+      else hipLaunchKernelGGL(k_alloc_scan_ofusion<false>, grid, block, 0, s, ms, p->depth, a, ds);
     }
   }
+  input_slot_in_use(p);
   if (ov) {
     HIP_TRY(hipEventRecord(p->ev_scan, p->side));
     p->scan_pending = true;
     HIP_TRY(hipGetLastError());
     return 1;
   }
+  // (serial schedule: occupancy bits in place, the new blocks' beam-start marks with the commit pass of the sweep / k_occ_commit)
+  p->occ_commit_due = true;
+  if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
   // keys[0] quirk of unique_multiscale (see k_zero_chain): needs the frame's complete key list, so a
   // row-sharded replica defers it to se_hip_alloc_commit (which sees every rank's list)
   if (!sdf && !a.sharded) {
@@ -981,7 +1004,7 @@ int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_
     // off the sweep -> raycast critical path -- and, like the scan, leaves occ[] to the sweep kernel, which
     // publishes the bits of every gathered list (the own list is one of them).
     DevMap md = p->map;
-    md.defer_occ = 1;
+    md.defer_occ = 1; md.defer_mark = 1;
     {
       ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT, p->side);
       hipLaunchKernelGGL(k_alloc_commit, dim3(64, nlists), dim3(SE_WG), 0, p->side, md, lists, nlists, (long long)stride_words);
@@ -989,7 +1012,7 @@ int se_hip_alloc_commit(se_hip_pipeline* p, const uint64_t* device_lists, int32_
     HIP_TRY(hipEventRecord(p->ev_scan, p->side));
     p->scan_pending = true;
     p->occ_lists = OccLists{lists, nlists, (long long)stride_words};
-  } else if (p->occ_commit_due && !p->scan_pending && !p->upload_on_side) {
+  } else if (p->occ_commit_due && !p->scan_pending) {
     // the scan rode in the previous raycast's launch on the main stream (k_raycast_scan) and left the bits of its own keys to the sweep, which is still
     // to come: no k_occ_commit launch between all-gather and sweep.  The peers' keys get their bits here (that raycast is over: stream order).
     ScopedTimer t(p, SE_HIP_K_ALLOC_COMMIT);
@@ -1071,6 +1094,8 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   if (!stage_runs_integration(frame, rate)) return 0;
   if (int r = check_overflow(p)) return r;
   if (int r = join_scan(p, true)) return r;
+  materialise_depth(p, p->stream);   // (a sweep without its scan: the stage API used out of order)
+  input_slot_in_use(p);
   const DevMap& m = p->map;
   const M4 pose = from_colmajor(pose_cm);
   const bool sdf = p->cfg.field_type == SE_HIP_FIELD_SDF;
@@ -1166,7 +1191,15 @@ int se_hip_integrate_sweep(se_hip_pipeline* p, const float pose_cm[16], const fl
   // the next frame's scan / depth upload may start behind this point: an event for the scan stream to wait on, or (host
   // gate) the sequence number of the raycast that follows
   if (p->host_gate) { p->gate_armed = true; p->gate_followed = false; p->gate_target = p->ray_seq + 1u; }
-  else hipEventRecord(p->ev_sweep, p->stream);
+  else {
+    hipEventRecord(p->ev_sweep, p->stream);
+    if (p->cur_in >= 0) {   // the input slot's last reader in a frame: what a later upload into the slot waits for (stage_input)
+      const int i = p->cur_in;
+      if (!p->in_done[i]) HIP_TRY(hipEventCreateWithFlags(&p->in_done[i], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(p->in_done[i], p->stream));
+      p->in_event[i] = true;
+    }
+  }
   HIP_TRY(hipGetLastError());
   return 1;
 }
@@ -1186,6 +1219,7 @@ static bool frame_can_fuse(se_hip_pipeline* p) {
 int se_hip_set_streaming(se_hip_pipeline* p, int32_t on) {
   if (int r = check(p)) return r;   // (switching off launches an outstanding raycast first)
   p->fuse = on != 0;
+  p->flush_streak = 0;
   return frame_can_fuse(p) ? 1 : 0;
 }
 int se_hip_frame_is_fused(se_hip_pipeline* p) {
@@ -1195,24 +1229,23 @@ int se_hip_frame_is_fused(se_hip_pipeline* p) {
 int se_hip_set_image_ring(se_hip_pipeline* p, float* device_ring, int32_t slots) {
   if (int r = check(p)) return r;
   if ((device_ring != nullptr) != (slots > 0)) return fail(SE_HIP_E_INVALID, "bad argument (ring and slots go together)");
-  p->ring = device_ring; p->ring_slots = device_ring ? slots : 0;
-  if (!device_ring) {
-    // vertex_ / normal_ stay what they were: the last raycast's images move back into the handle's own buffers
+  if (p->ring && device_ring != p->ring && p->vertex != p->vertex_own) {
+    // leaving a ring (for none, or for another one: ADVICE r05 -- the caller may free the old ring when this returns): vertex_ / normal_ stay what they
+    // were, the last raycast's images move into the handle's own buffers
     const size_t bytes = (size_t)p->cfg.width * p->cfg.height * 3 * sizeof(float);
-    if (p->vertex != p->vertex_own) {
-      HIP_TRY(hipMemcpyAsync(p->vertex_own, p->vertex, bytes, hipMemcpyDeviceToDevice, p->stream));
-      HIP_TRY(hipMemcpyAsync(p->normal_own, p->normal, bytes, hipMemcpyDeviceToDevice, p->stream));
-      HIP_TRY(hipStreamSynchronize(p->stream));   // (the caller may free the ring when this returns)
-    }
+    HIP_TRY(hipMemcpyAsync(p->vertex_own, p->vertex, bytes, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->normal_own, p->normal, bytes, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
     p->vertex = p->vertex_own; p->normal = p->normal_own;
   }
+  p->ring = device_ring; p->ring_slots = device_ring ? slots : 0;
   return SE_HIP_OK;
 }
 extern "C++" int flush_pending_raycast(se_hip_pipeline* p) {
   if (!p->has_pending) return SE_HIP_OK;
-  p->has_pending = false;
   InFrame guard(p);      // (the nested check() must not recurse)
   const int r = se_hip_raycast(p, p->pend_pose, p->pend_k, p->pend_mu, p->pend_frame);
+  if (r >= 0) p->has_pending = false;   // (an error -- a pool overflow not yet acknowledged -- leaves it pending: launched by the first call that succeeds)
   return r < 0 ? r : SE_HIP_OK;
 }
 
@@ -1239,7 +1272,7 @@ int se_hip_raycast_deferred(se_hip_pipeline* p, const float pose[16], const floa
   if (!finite_pose(pose, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
   if (p->has_pending) { if (int r = flush_pending_raycast(p)) return r; }   // two raycasts without an integration between them
   if (!(frame > 2)) return 0;      // DenseSLAMSystem.cpp:195
-  if (!frame_can_fuse(p)) return se_hip_raycast(p, pose, k, mu, frame);
+  if (!frame_can_fuse(p) || p->flush_streak >= 2) return se_hip_raycast(p, pose, k, mu, frame);
   if (int r = check_overflow(p)) return r;
   std::memcpy(p->pend_pose, pose, sizeof p->pend_pose); std::memcpy(p->pend_k, k, sizeof p->pend_k);
   p->pend_mu = mu; p->pend_frame = frame; p->has_pending = true;
@@ -1254,7 +1287,7 @@ int se_hip_frame(se_hip_pipeline* p, const float* device_depth_m, const float po
   if (int r = check(p)) return r;
   if (!pose || !k || rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
   if (!finite_pose(pose, k)) return fail(SE_HIP_E_INVALID, "non-finite pose or intrinsics");
-  if (device_depth_m) p->depth = device_depth_m;
+  if (device_depth_m) { p->depth = device_depth_m; p->cur_in = -1; p->in_pending.kind = 0; }
   int ran = 0;
   int r = se_hip_integrate(p, pose, k, rate, mu, frame);
   if (r < 0) return r;
@@ -1278,7 +1311,7 @@ int se_hip_raycast(se_hip_pipeline* p, const float pose_cm[16], const float k[4]
   select_image_target(p, frame);
   const DevMap& m = p->map;
   RayLaunchArgs L = make_ray_args(p, pose_cm, k, mu);
-  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; }
+  if (p->host_gate) { L.a.gate = p->gate_host; L.a.gate_seq = ++p->ray_seq; if (p->gate_armed) p->gate_followed = true; input_slots_followed(p, L.a.gate_seq); }
   const RayArgs& a = L.a;
   const size_t smem = L.smem;
   const dim3 grid = L.grid, block(SE_WG_RAY);
@@ -1403,6 +1436,8 @@ int se_hip_track(se_hip_pipeline* p, const float k[4], float icp_threshold, uint
     std::memset(p->icp_host, 0, sizeof(IcpHostRecord));
   }
   // pyramid (DenseSLAMSystem.cpp:149-163): scaled_depth_[0] is the current depth image
+  materialise_depth(p, s);
+  input_slot_in_use(p);
   const float* d0 = p->depth;
   if (p->filter_input) {   // DenseSLAMSystem.cpp:132-135; gaussian_: DenseSLAMSystem.cpp:111-118
     Gauss5 G;
@@ -1511,7 +1546,7 @@ int se_hip_frame_tracked(se_hip_pipeline* p, const float* device_depth_m, const 
                          const int32_t* pyramid, int32_t n_levels, float pose_cm[16], uint32_t integration_rate, float mu, uint32_t frame) {
   if (int r = check(p)) return r;
   if (!k || !pose_cm || !pyramid || integration_rate == 0 || tracking_rate == 0) return fail(SE_HIP_E_INVALID, "bad argument");
-  if (device_depth_m) p->depth = device_depth_m;
+  if (device_depth_m) { p->depth = device_depth_m; p->cur_in = -1; p->in_pending.kind = 0; }
   int out = 0;
   int r = se_hip_track(p, k, icp_threshold, tracking_rate, frame, pyramid, n_levels, pose_cm);
   if (r < 0) return r;
@@ -1604,6 +1639,8 @@ int se_hip_render_depth(se_hip_pipeline* p, uint8_t* host_rgbw) {
   if (int r = join_scan(p)) return r;
   if (int r = render_target(p)) return r;
   const int n = p->cfg.width * p->cfg.height;
+  materialise_depth(p, p->stream);
+  input_slot_in_use(p);
   hipLaunchKernelGGL(k_render_depth, dim3((n + 255) / 256), dim3(256), 0, p->stream, p->rgbw, p->depth, n, 0.4f, 4.0f);
   HIP_TRY(hipGetLastError());
   return render_download(p, host_rgbw);

@@ -119,9 +119,9 @@ __device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, 
 }
 
 // `want` = false: the lane only accompanies the others of its wave (shared counter updates, se_wave_take); the callers pass the lanes that found the
-// entry empty.  A block's beam-start marks (se_mark_coarse) are deferred with its occupancy bits (m.defer_occ: the scan runs beside the previous frame's
-// raycast; se_occ_commit sets both before the next raycast) -- r05 marked in place, up to 18 atomics and a dependent read per new block on the scan's
-// critical path; a block inserted beside a raycast holds initValue() and is invisible to it either way.
+// entry empty.  A block's beam-start marks (se_mark_coarse) are left to se_occ_commit (m.defer_mark: every allocation scan -- only a raycast reads the
+// marks, and the sweep in front of it walks the scan's key list anyway) -- r05 marked in place, up to 18 atomics and a dependent read per new block on the
+// scan's critical path (profiles/r06a_insert_ab.log); a block inserted beside a raycast holds initValue() and is invisible to it either way.
 __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int x, int y, int z, bool want = true) {
   uint32_t* e = m.tab + tab_index(m, level, x, y, z);
   bool won = false;
@@ -139,7 +139,7 @@ __device__ __forceinline__ bool se_insert_octant(const DevMap& m, int level, int
         m.bactive[slot] = 1;  // allocate_level: active(true), octree.hpp:841
         occ_set(m, level, x, y, z);
         { const uint32_t lin = block_linear(m, x, y, z); atomicOr(&m.lbits[lin >> 5], 1u << (lin & 31u)); }   // (never deferred: a reader that sees the bit early finds PENDING or a brick of initValue())
-        if (SE_DEFER_MARK == 0 || (SE_DEFER_MARK == 1 && !m.defer_occ)) se_mark_coarse(m, x, y, z);
+        if (SE_DEFER_MARK == 0 || (SE_DEFER_MARK == 1 && !m.defer_mark)) se_mark_coarse(m, x, y, z);
         atomicExch(e, slot + 1u);
       }
     }
@@ -188,6 +188,21 @@ template <bool STATS> __device__ __forceinline__ void se_stat_add(const DevMap& 
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&m.stats[which], v);
   }
+}
+
+// Host-resident input (r06).  se_hip_upload_depth / se_hip_upload_depth_mm leave the caller's image in pinned host memory; the first kernel that
+// needs float_depth_ reads it from there (zero copy over PCIe) and materialises the device image `out` on the way: the allocation scan, one thread per
+// pixel, is that kernel on the frame path -- no DMA packet, no conversion launch, no second queue between the sensor buffer and the scan.  kind 1 =
+// uint16 millimetres of an image `ratio` times the computation size (mm2metersKernel, se_denseslam/src/preprocessing.cpp:161-188: in[x * ratio + in_w * y
+// * ratio] / 1000.0f), 2 = float metres (float_depth_ itself), 0 = nothing pending: read the device image.
+struct DepthSrc { const void* host; float* out; int kind, in_w, ratio; };
+__device__ __forceinline__ float se_depth_at(const DepthSrc& ds, const float* __restrict__ depthmap, int x, int y, int W) {
+  if (ds.kind == 0) return depthmap[x + y * W];
+  float d;
+  if (ds.kind == 1) d = ((const unsigned short*)ds.host)[x * ds.ratio + ds.in_w * y * ds.ratio] / 1000.0f;
+  else d = ((const float*)ds.host)[x + y * W];
+  ds.out[x + y * W] = d;
+  return d;
 }
 
 struct AllocArgs {
@@ -266,22 +281,30 @@ __device__ __forceinline__ int se_cvt_flr(float x) { int r; asm("v_cvt_flr_i32_f
 // (the body of the kernel, so that k_raycast_scan can run it as part of a raycast launch: `bid` = workgroup index within the scan's grid,
 // s_blk_all = SE_SCAN_SLOTS * SE_WG_SCAN words of LDS)
 template <bool STATS, bool DENSE>
-__device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __restrict__ depthmap, const AllocArgs& a, uint32_t* s_blk_all, int bid) {
+__device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __restrict__ depthmap, const AllocArgs& a, uint32_t* s_blk_all, int bid, const DepthSrc& ds) {
   uint32_t* s_blk = s_blk_all + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
   int x, y;
   bool in_image;
   {
-    // a wave scans an 8x8 pixel tile: its rays cross the same 1-2 blocks per step (64 pixels of a row measured the same)
+    // a wave scans an 8x8 pixel tile: its rays cross the same 1-2 blocks per step (64 pixels of a row measured the same) ...
     const int lane = threadIdx.x & 63;
     const int tile = bid * (SE_WG_SCAN / 64) + (threadIdx.x >> 6);
-    const int tiles_x = (a.W + 7) >> 3;
-    x = (tile % tiles_x) * 8 + (lane & 7);
-    y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
+    if (ds.kind == 0) {
+      const int tiles_x = (a.W + 7) >> 3;
+      x = (tile % tiles_x) * 8 + (lane & 7);
+      y = a.row_begin + (tile / tiles_x) * 8 + (lane >> 3);
+    } else {
+      // ... and 64 pixels of a row when the image is still in host memory (DepthSrc): the wave's read is one contiguous 128 / 256-byte piece -- host
+      // memory is not cached on the device, the 16-byte row pieces of an 8x8 tile would each cross PCIe as a request of their own
+      const int tiles_x = (a.W + 63) >> 6;
+      x = (tile % tiles_x) * 64 + lane;
+      y = a.row_begin + tile / tiles_x;
+    }
     in_image = x < a.W && y < a.row_end;
   }
   if (in_image) {
-    const float depth = depthmap[x + y * a.W];
+    const float depth = se_depth_at(ds, depthmap, x, y, a.W);
     if (!(depth == 0)) {
       const f3 worldVertex = m34_mul_h(a.kpose, {(x + 0.5f) * depth, (y + 0.5f) * depth, depth});
       const f3 camera = {a.cam[0], a.cam[1], a.cam[2]};
@@ -322,9 +345,9 @@ __device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __r
   se_stat_add<STATS>(m, S_NEWKEYS, newk);
 }
 template <bool STATS, bool DENSE>
-__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const float* __restrict__ depthmap, AllocArgs a, DepthSrc ds) {
   __shared__ uint32_t s_blk_all[SE_SCAN_SLOTS * SE_WG_SCAN];
-  se_scan_sdf_wg<STATS, DENSE>(m, depthmap, a, s_blk_all, (int)blockIdx.x);
+  se_scan_sdf_wg<STATS, DENSE>(m, depthmap, a, s_blk_all, (int)blockIdx.x, ds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,14 +356,14 @@ __global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_sdf(DevMap m, const f
 // three-stage step size; coarse steps insert childless octants at levels leaf-1 / leaf-2.
 // ------------------------------------------------------------------------------------------
 template <bool STATS>
-__device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float* __restrict__ depthmap, const AllocArgs& a, int bid) {
+__device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float* __restrict__ depthmap, const AllocArgs& a, int bid, const DepthSrc& ds) {
   const int npix = (a.row_end - a.row_begin) * a.W;
   const int pid = bid * SE_WG_SCAN + threadIdx.x;
   unsigned long long probes = 0, newk = 0;
   if (pid < npix) {
     const int x = pid % a.W;
     const int y = a.row_begin + pid / a.W;
-    const float depth = depthmap[x + y * a.W];
+    const float depth = se_depth_at(ds, depthmap, x, y, a.W);
     if (!(depth == 0)) {
       int tree_depth = m.max_level;
       float stepsize = a.voxel;
@@ -386,8 +409,8 @@ __device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float*
   se_stat_add<STATS>(m, S_NEWKEYS, newk);
 }
 template <bool STATS>
-__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a) {
-  se_scan_ofusion_wg<STATS>(m, depthmap, a, (int)blockIdx.x);
+__global__ __launch_bounds__(SE_WG_SCAN) void k_alloc_scan_ofusion(DevMap m, const float* __restrict__ depthmap, AllocArgs a, DepthSrc ds) {
+  se_scan_ofusion_wg<STATS>(m, depthmap, a, (int)blockIdx.x, ds);
 }
 
 // Octree::allocate for key lists gathered from other ranks (multi-GPU): one thread per key.
@@ -1068,6 +1091,7 @@ struct RayArgs {
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
                        // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
+  unsigned long long* wlog;   // -DSE_WAVE_PROBE builds only (tools/wave_timeline.py): per-wave clock records, pinned host memory; null otherwise
 };
 
 struct BlkCache { int bx, by, bz; uint32_t e; };
@@ -2218,6 +2242,11 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
   uint32_t* s_par = smem + a.cache_words;
   float* s_tmax = (float*)(s_par + a.stack_depth * SE_WG_RAY);
   if (a.gate && bid == 0 && threadIdx.x == 0) *(volatile uint32_t*)a.gate = a.gate_seq;
+#ifdef SE_WAVE_PROBE
+  const unsigned long long w_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long w_t1 = w_t0, w_t2 = w_t0;
+  int dbg_trips = 0, dbg_batches = 0;
+#endif
   const unsigned long long tk0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
   // LDS staging of the occupancy words, split in two: the global loads are issued here, the LDS writes and the barrier
   // follow the ray set-up inside se_first_leaf (a per-level copy of only the used words was slower)
@@ -2276,6 +2305,9 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     const RaySpan full = se_first_leaf<SHALLOW>(m, a, org, dir, s_occ, s_par, s_tmax, SeNoHook(), redo);
     if (redo) span = {full.tcmin, full.tmax, span.trips + full.trips};
   }
+#ifdef SE_WAVE_PROBE
+  w_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (in_image) {
     const float t_min = span.tcmin, tfar = span.tmax;
     if (STATS) tk2 = __builtin_amdgcn_s_memtime();
@@ -2288,6 +2320,9 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
       my_cost = (unsigned)SE_COST_BATCH * rc.n_batch;
     }
     my_cost += (unsigned)span.trips;
+#ifdef SE_WAVE_PROBE
+    dbg_trips = span.trips; dbg_batches = (int)((my_cost - (unsigned)span.trips) / (unsigned)SE_COST_BATCH);
+#endif
     if (STATS) tk3 = __builtin_amdgcn_s_memtime();
     float* v = vertex + 3 * (size_t)(px + py * a.W);
     float* n = normal + 3 * (size_t)(px + py * a.W);
@@ -2307,6 +2342,23 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
       n[0] = -2.f; n[1] = 0.f; n[2] = 0.f;
     }
   }
+#ifdef SE_WAVE_PROBE
+  // lane 0 of every wave: clocks (100 MHz) at entry / after the first-leaf search / at exit, HW_ID + XCC_ID, the wave maxima of trips and march batches
+  {
+    for (int o = 32; o > 0; o >>= 1) { dbg_trips = max(dbg_trips, __shfl_xor(dbg_trips, o)); dbg_batches = max(dbg_batches, __shfl_xor(dbg_batches, o)); }
+    w_t2 = __builtin_amdgcn_s_memrealtime();
+    if (a.wlog && (threadIdx.x & 63) == 0) {
+      const size_t wi = (size_t)bid * (SE_WG_RAY / 64) + (threadIdx.x >> 6);
+      if (wi < 32768) {
+        a.wlog[4 * wi] = w_t0;
+        a.wlog[4 * wi + 1] = w_t2;
+        a.wlog[4 * wi + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+        a.wlog[4 * wi + 3] = ((unsigned long long)(uint32_t)min((unsigned long long)(w_t1 - w_t0), 0xFFFFull) << 48) | ((unsigned long long)(uint32_t)(tile_slot & 0xFFFF) << 32) |
+                             ((unsigned long long)(dbg_trips & 0x3FF) << 20) | ((unsigned long long)(dbg_batches & 0x3FF) << 10);
+      }
+    }
+  }
+#endif
   if (a.tile_cost) {
     // wave maximum through the (now idle) first stack slot of this wave's lane 0; LDS operations of one wave are ordered
     uint32_t* slot = s_par + (threadIdx.x & ~63);
@@ -2349,21 +2401,13 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast(DevMap m, RayA
 static_assert(SE_WG_RAY == SE_WG_SCAN, "the fused raycast + scan launch uses one workgroup size");
 template <bool OFUSION, bool DENSE, bool SHALLOW, bool O32>
 __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast_scan(DevMap m, RayArgs a, float* __restrict__ vertex, float* __restrict__ normal, int ray_wgs,
-                                                                         DevMap ms, const float* __restrict__ depthmap, AllocArgs sa, int scan_wgs, int first_round) {
+                                                                         DevMap ms, const float* __restrict__ depthmap, AllocArgs sa, DepthSrc ds) {
   extern __shared__ uint32_t smem[];
-  // Dispatch order = blockIdx order.  The first `first_round` workgroups (what the chip holds at once) are the raycast's; behind them raycast and
-  // scan workgroups alternate until one kind runs out.  With all scan workgroups at the very end (the first version) a launch of several rounds --
-  // 1280x960: four -- only started scanning when its last raycast round was dispatched: 362 us at 2048^3 for a 195 us raycast and a 160 us scan.
-  int bid, is_scan;
-  {
-    const int b = (int)blockIdx.x, F = min(first_round, ray_wgs), I = min(ray_wgs - F, scan_wgs);
-    if (b < F) { is_scan = 0; bid = b; }
-    else {
-      const int j = b - F;
-      if (j < 2 * I) { is_scan = j & 1; bid = is_scan ? (j >> 1) : F + (j >> 1); }
-      else { const int k = j - 2 * I; is_scan = (ray_wgs - F > I) ? 0 : 1; bid = is_scan ? I + k : F + I + k; }
-    }
-  }
+  // Dispatch order = blockIdx order: the raycast's workgroups first -- all of them resident at once (the host only fuses launches whose raycast fits the
+  // chip in one round, frame_can_fuse) -- the scan's fill in as those retire.  (Letting scan workgroups in earlier delays raycast waves: profiles/r05p;
+  // fusing launches of several raycast rounds, 1280x960, lost to the two-queue schedule: profiles/r04p.)
+  const int is_scan = (int)blockIdx.x >= ray_wgs;
+  const int bid = is_scan ? (int)blockIdx.x - ray_wgs : (int)blockIdx.x;
   if (!is_scan) {
     // the raycast's waves are the launch's critical path: they start at issue priority 1, the scan's (priority 0) take the slots they leave.  Same box,
     // two repetitions (profiles/r04x_fused_ray_prio_ab.log): +1.1 % frames/s at 512^3, +2 % OFusion, 0 on the stress stream, -1 % at 1024^3 (there the scan,
@@ -2372,8 +2416,8 @@ __global__ __launch_bounds__(SE_WG_RAY) SE_RAY_OCC void k_raycast_scan(DevMap m,
     se_raycast_wg<OFUSION, false, DENSE, SHALLOW, O32>(m, a, vertex, normal, smem, bid);
     return;
   }
-  if (OFUSION) se_scan_ofusion_wg<false>(ms, depthmap, sa, bid);
-  else se_scan_sdf_wg<false, DENSE>(ms, depthmap, sa, smem, bid);   // (its SE_SCAN_SLOTS * SE_WG_SCAN words fit the raycast's LDS allocation: checked by the host)
+  if (OFUSION) se_scan_ofusion_wg<false>(ms, depthmap, sa, bid, ds);
+  else se_scan_sdf_wg<false, DENSE>(ms, depthmap, sa, smem, bid, ds);   // (its SE_SCAN_SLOTS * SE_WG_SCAN words fit the raycast's LDS allocation: checked by the host)
 }
 
 // map read-back: packs the bricks named by slots[] (already in the caller's order) contiguously
@@ -2419,10 +2463,11 @@ __global__ void k_fill_bricks(float* __restrict__ p, float vx, float vy, size_t 
 __global__ void k_fill(float* __restrict__ p, float v, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
-// mm2metersKernel (se_denseslam/src/preprocessing.cpp:161-188) on the device
-__global__ void k_mm2meters(float* __restrict__ out, int ow, int oh, const unsigned short* __restrict__ in, int iw, int ratio) {
+// mm2metersKernel (se_denseslam/src/preprocessing.cpp:161-188) on the device, for the consumers of float_depth_ that come before a frame's allocation
+// scan (tracking, renderDepth) and for row-sharded replicas, whose scan sees only its own rows: materialises a host-resident input (DepthSrc)
+__global__ void k_depth_from_host(DepthSrc ds, int ow, int oh) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x < ow && y < oh) out[x + ow * y] = in[x * ratio + iw * y * ratio] / 1000.0f;
+  if (x < ow && y < oh) se_depth_at(ds, nullptr, x, y, ow);
 }
 
 // ------------------------------------------------------------------------------------------
