@@ -50,8 +50,10 @@ struct DevMap {
                                   // within one coarse cell of any point of this cell.  Only ever set (never cleared: blocks are never freed).  The second
                                   // half of the allocation holds the same grid undilated ("a block exists in this cell": se_mark_coarse).
   int clevel;
-  uint32_t* fbits;                // the same at the block grid's own resolution (level leaf_level): set for every cell within one BLOCK of an allocated block;
-                                  // 32 KB at 512^3, 256 KB at 1024^3, 2 MB at 2048^3 (second stage of the beam start); null if leaf_level <= clevel
+  uint32_t* fbits;                // the same on a finer grid, level flevel = min(leaf_level, 6) (7.5 cm cells at 4.8 m: the margin an 8x8-pixel beam of a 640x480 camera
+                                  // needs at working distance; r05 used the block grid itself, whose margin at 1024^3 -- 3.75 cm -- the beam does not fit): set for every cell
+                                  // within one cell of an allocated block; 32 KB (second stage of the beam start, OFusion leap); null if flevel <= clevel
+  int flevel;
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int defer_mark;                 // 1: insertions do not mark cbits / fbits (se_occ_commit does, from the key list, before the next raycast: every allocation scan)

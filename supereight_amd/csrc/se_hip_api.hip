@@ -5,6 +5,9 @@
 #include "../../include/se_hip.h"
 
 #include <hip/hip_runtime.h>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -330,13 +333,14 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
   // beam start: 64 samples on a tile's centre ray, half a coarse cell apart (or whatever spacing covers near .. far)
   a.beam = (p->beam >= 2 && !m.fbits) ? 1 : p->beam;
-  a.beam_cellf = m.dim / (float)(1 << m.leaf_level);
-  a.beam_inv_cellf = (float)(1 << m.leaf_level) / m.dim;
+  const int flevel = m.fbits ? m.flevel : m.leaf_level;   // (no fbits: leaf_level <= clevel, the coarse grid is the block grid)
+  a.beam_cellf = m.dim / (float)(1 << flevel);
+  a.beam_inv_cellf = (float)(1 << flevel) / m.dim;
   a.beam_dt2 = 0.4f * a.beam_cellf;
   if (a.beam >= 2) {
-    // the fine stage pays (one more dependent load per wave, of a bitmap that is 256 KB at 1024^3) only where its clearance bound can hold at working
-    // distance: an 8x8 pixel beam at 3/4 of the far plane must fit inside one block's margin (true at 512^3 / 640x480, not at 1024^3: measured +-0 there
-    // in the pipeline and +8 us on a stand-alone raycast, profiles/r05o_beam2_ab.log)
+    // the fine stage pays (one more dependent load per wave) only where its clearance bound can hold at working distance: an 8x8 pixel beam at 3/4 of the
+    // far plane must fit inside one cell's margin.  r05 tested on the block grid, where that fails from 1024^3 on (3.75 cm blocks); the level-6 grid (7.5 cm)
+    // holds it for any 640x480-like camera, at every volume resolution
     const float rad = 1.05f * std::hypot(0.5f * (SE_TILE_W - 1) / std::fabs(k[0]), 0.5f * (SE_TILE_H - 1) / std::fabs(k[1])) + a.epsilon;
     if (!((0.75f * a.farp + 0.5f * a.beam_dt2) * rad + 0.5f * a.beam_dt2 <= 0.9f * a.beam_cellf)) a.beam = 1;
   }
@@ -346,7 +350,7 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.inv_dim = 1.f / m.dim;
   // OFusion march: leap over block-free space on the dilated block grid (fbits; for leaf levels <= 5 the coarse grid IS the block grid)
   a.leap_bits = !p->of_leap ? nullptr : m.fbits ? m.fbits : (m.clevel == m.leaf_level ? m.cbits : nullptr);
-  a.leap_level = m.leaf_level;
+  a.leap_level = flevel;
   a.leap_dt = 0.9f * a.beam_cellf;
   a.wlog = nullptr;
 #ifdef SE_WAVE_PROBE
@@ -608,7 +612,8 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->cbits_words = std::max<size_t>(1, ((size_t)1 << (3 * m.clevel)) / 32);
   ALLOC(m.cbits, 2 * p->cbits_words * sizeof(uint32_t));   // [dilated bits][undilated bits of the same grid: se_mark_coarse]
   m.fbits = nullptr;
-  if (p->leaf_level > m.clevel) { p->fbits_words = cells / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
+  m.flevel = std::min(p->leaf_level, 6);      // cells of dim / 64 (7.5 cm at 4.8 m): second stage of the beam start, OFusion leap
+  if (m.flevel > m.clevel) { p->fbits_words = ((size_t)1 << (3 * m.flevel)) / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
   m.vy = m.vx + 512;
   ALLOC(m.bpos, cap * sizeof(uint32_t));
@@ -753,6 +758,27 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
   return SE_HIP_OK;
 }
 
+// The caller's image -> a pinned slot.  The device reads the slot over PCIe exactly once and the CPU never again: streaming (non-temporal) stores keep the
+// 0.6-1.2 MB out of the CPU's caches -- no read-for-ownership of the destination lines, and the device's reads are served by memory instead of by snoops
+// of dirty lines (x86-64; elsewhere memcpy).
+static void copy_to_pinned(void* dst, const void* src, size_t bytes) {
+#if defined(__x86_64__)
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0 && bytes >= 4096) {
+    const __m128i* s = (const __m128i*)src;
+    __m128i* d = (__m128i*)dst;
+    const size_t n = bytes / 64;
+    for (size_t i = 0; i < n; ++i) {
+      const __m128i a = _mm_load_si128(s + 4 * i), b = _mm_load_si128(s + 4 * i + 1), c = _mm_load_si128(s + 4 * i + 2), e = _mm_load_si128(s + 4 * i + 3);
+      _mm_stream_si128(d + 4 * i, a); _mm_stream_si128(d + 4 * i + 1, b); _mm_stream_si128(d + 4 * i + 2, c); _mm_stream_si128(d + 4 * i + 3, e);
+    }
+    _mm_sfence();
+    if (bytes & 63) std::memcpy((char*)dst + n * 64, (const char*)src + n * 64, bytes & 63);
+    return;
+  }
+#endif
+  std::memcpy(dst, src, bytes);
+}
+
 // Host image -> the next slot of the pinned input ring (see se_hip_pipeline::in_host); nothing is enqueued.
 static int stage_input(se_hip_pipeline* p, const void* host, size_t bytes, int kind, int in_w, int ratio) {
   constexpr int R = se_hip_pipeline::kIn;
@@ -780,7 +806,7 @@ static int stage_input(se_hip_pipeline* p, const void* host, size_t bytes, int k
     HIP_TRY(hipStreamSynchronize(p->stream));
   }
   p->in_state[i] = 0; p->in_event[i] = false;
-  std::memcpy(p->in_host[i], host, bytes);
+  copy_to_pinned(p->in_host[i], host, bytes);
   p->in_pending = DepthSrc{p->in_host[i], p->depth_ring[i], kind, in_w, ratio};
   p->depth = p->depth_ring[i];
   p->cur_in = i;

@@ -115,7 +115,7 @@ __device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, 
     atomicOr(cown + (idx >> 5), bit);
     se_mark_dilated(m.cbits, C, cx, cy, cz);
   }
-  if (m.fbits) se_mark_dilated(m.fbits, m.leaf_level, bx, by, bz);
+  if (m.fbits) { const int fs = m.leaf_level - m.flevel; se_mark_dilated(m.fbits, m.flevel, bx >> fs, by >> fs, bz >> fs); }
 }
 
 // `want` = false: the lane only accompanies the others of its wave (shared counter updates, se_wave_take); the callers pass the lanes that found the
@@ -1570,9 +1570,20 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
   const uint32_t staged_parents = a.cache_codes >> 3;   // parents below this code have their sibling byte in LDS
   unsigned long long gp_bits = 0ull;   // the 64 leaf bits below the node two levels above the leaves the ray is in
   uint32_t gp_code = 0u;
+  // Volumes > 512^3 (r06): the sibling bytes of the parents one and two levels above the leaf parents (1024^3: level 5; 2048^3: levels 5 and 6) are not
+  // staged either, and r05 read each from global memory when its node was entered or popped back to -- a dependent round trip inside the trip, 0.6 us per
+  // trip for a wave alone on its SIMD against 0.26 us at 512^3, and the launch ends with rays of 55-60 trips (profiles/r06b_wave_timeline_sdf1024_closed.txt).
+  // They now come the way the leaf bits do: the 8 sibling bytes of a node's children are one aligned 8-byte group, fetched when the node is entered --
+  // a trip or more before the first child is -- and kept while the ray is below that node (a pop returns to a node the ray came down through).
+  unsigned long long g2_bits = 0ull, g3_bits = 0ull;   // groups of the nodes three / four levels above the leaves: the sibling bytes of their children
+  uint32_t g2_code = 0u, g3_code = 0u;
   before_loop();
-  // sibling byte of parent P: staged -> LDS; leaf parent -> byte (P & 7) of gp_bits; else (volumes > 512^3) global
-#define SE_SIB_OF(P) ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)] : (uint32_t)occ_bytes[(P)])
+  // sibling byte of parent P, D levels above the leaf parents: staged -> LDS; from its parent's group; else global (never at <= 2048^3)
+#define SE_SIB_OF(P, D)                                                                                                                      \
+  ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)]                                                                                  \
+   : ((D) == 1 && ((P) >> 3) == g2_code) ? ((uint32_t)(g2_bits >> (((P) & 7u) << 3)) & 0xFFu)                                                 \
+   : ((D) == 2 && ((P) >> 3) == g3_code) ? ((uint32_t)(g3_bits >> (((P) & 7u) << 3)) & 0xFFu)                                                 \
+                                          : (uint32_t)occ_bytes[(P)])
   uint32_t sib = s_occ8[1];   // the root's children: word 0 of the occupancy bits is always staged
   int guard = 0;
   const int max_trips = (!live || redo) ? 0 : 4096;
@@ -1599,8 +1610,11 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
         if ((parent >> 3) != gp_code) { gp_code = parent >> 3; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)gp_code << 3)); }
         sib = (uint32_t)(gp_bits >> ((parent & 7u) << 3)) & 0xFFu;
       } else {
-        if (scale == a.min_scale + 1) { gp_code = parent; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
-        sib = SE_SIB_OF(parent);
+        const int dl = scale - a.min_scale;   // levels above the leaf parents
+        if (dl == 1) { gp_code = parent; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
+        else if (!SHALLOW && dl == 2 && !((parent << 3) < staged_parents)) { g2_code = parent; g2_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
+        else if (!SHALLOW && dl == 3 && !((parent << 3) < staged_parents)) { g3_code = parent; g3_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
+        sib = SE_SIB_OF(parent, dl);
       }
     } else {
       // advance_ray (ray_iterator.hpp:116-167)
@@ -1620,7 +1634,7 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
           pos.x = __uint_as_float(__float_as_uint(pos.x) & keep);
           pos.y = __uint_as_float(__float_as_uint(pos.y) & keep);
           pos.z = __uint_as_float(__float_as_uint(pos.z) & keep);
-          sib = SE_SIB_OF(parent);
+          sib = SE_SIB_OF(parent, scale - a.min_scale);
         }
       }
     }
@@ -2194,8 +2208,11 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
   const f3 p = f3_add(org, f3_scale_r(dc, ti));
   const int C = m.clevel;
   const int cx = se_cvt_flr(p.x * a.beam_inv_cell), cy = se_cvt_flr(p.y * a.beam_inv_cell), cz = se_cvt_flr(p.z * a.beam_inv_cell);
-  const bool in = (uint32_t)(cx | cy | cz) < (1u << C);     // outside the volume: no blocks there
-  const uint32_t idx = in ? (((uint32_t)cz << (2 * C)) | ((uint32_t)cy << C) | (uint32_t)cx) : 0u;
+  // A sample outside the volume sees no blocks -- unless it lies in the one-cell shell around it, within a cell of whatever is allocated on that face:
+  // the shell takes the dilated bit of the boundary cell it touches (which covers every cell within one of the sample's own)
+  const int nC = 1 << C;
+  const bool in = (uint32_t)(cx + 1) <= (uint32_t)nC && (uint32_t)(cy + 1) <= (uint32_t)nC && (uint32_t)(cz + 1) <= (uint32_t)nC;
+  const uint32_t idx = in ? (((uint32_t)min(max(cz, 0), nC - 1) << (2 * C)) | ((uint32_t)min(max(cy, 0), nC - 1) << C) | (uint32_t)min(max(cx, 0), nC - 1)) : 0u;
   const uint32_t w = m.cbits[idx >> 5];
   const bool occupied = in && ((w >> (idx & 31u)) & 1u);
   const bool clear = !occupied && ((ti + 0.5f * a.beam_dt) * rad + 0.5f * a.beam_dt <= 0.9f * a.beam_cell);
@@ -2203,15 +2220,16 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
   const int j = blocked ? (int)__builtin_ctzll(blocked) : 64;
   float t_safe = j < 1 ? 0.f : a.nearp + ((float)j - 0.5f) * a.beam_dt;
   if (a.beam >= 2) {
-    // second stage, from the end of the coarse run on: the same test against fbits, the block grid's own resolution dilated by one block -- the coarse
-    // stage stops 15-45 cm in front of the first block near the beam (one coarse cell of dilation, one of quantisation, half a sample), this one 1-2 blocks
+    // second stage, from the end of the coarse run on: the same test against fbits, the level-min(leaf, 6) grid dilated by one of its cells -- the coarse
+    // stage stops 15-45 cm in front of the first block near the beam (one coarse cell of dilation, one of quantisation, half a sample), this one 7-15 cm
     const float t1 = fmaxf(t_safe, a.nearp);
     const float tf = t1 + ((float)lane + 0.5f) * a.beam_dt2;
     const f3 pf = f3_add(org, f3_scale_r(dc, tf));
-    const int F = m.leaf_level;
+    const int F = m.flevel;
     const int fx = se_cvt_flr(pf.x * a.beam_inv_cellf), fy = se_cvt_flr(pf.y * a.beam_inv_cellf), fz = se_cvt_flr(pf.z * a.beam_inv_cellf);
-    const bool inf = (uint32_t)(fx | fy | fz) < (1u << F);
-    const uint32_t fidx = inf ? (((uint32_t)fz << (2 * F)) | ((uint32_t)fy << F) | (uint32_t)fx) : 0u;
+    const int nF = 1 << F;
+    const bool inf = (uint32_t)(fx + 1) <= (uint32_t)nF && (uint32_t)(fy + 1) <= (uint32_t)nF && (uint32_t)(fz + 1) <= (uint32_t)nF;   // (the shell: as above)
+    const uint32_t fidx = inf ? (((uint32_t)min(max(fz, 0), nF - 1) << (2 * F)) | ((uint32_t)min(max(fy, 0), nF - 1) << F) | (uint32_t)min(max(fx, 0), nF - 1)) : 0u;
     const uint32_t fw = m.fbits[fidx >> 5];
     const bool clear2 = !(inf && ((fw >> (fidx & 31u)) & 1u)) && ((tf + 0.5f * a.beam_dt2) * rad + 0.5f * a.beam_dt2 <= 0.9f * a.beam_cellf);
     const unsigned long long blocked2 = __ballot(!clear2);

@@ -150,8 +150,11 @@ template <typename VT> static float beam_start(const Octree<VT>& m, const std::v
     const float ti = nearP + (float)l * dt;
     const V3f p = org + dc * ti;
     const int cx = (int)floorf(p.x * inv_cell), cy = (int)floorf(p.y * inv_cell), cz = (int)floorf(p.z * inv_cell);
-    const bool in = (uint32_t)(cx | cy | cz) < (1u << C);
-    const uint32_t idx = in ? (((uint32_t)cz << (2 * C)) | ((uint32_t)cy << C) | (uint32_t)cx) : 0u;
+    // (a sample in the one-cell shell around the volume takes the dilated bit of the boundary cell it touches, as the kernel does)
+    const int nC = 1 << C;
+    auto cl = [](int v, int n) { return std::min(std::max(v, 0), n - 1); };
+    const bool in = (uint32_t)(cx + 1) <= (uint32_t)nC && (uint32_t)(cy + 1) <= (uint32_t)nC && (uint32_t)(cz + 1) <= (uint32_t)nC;
+    const uint32_t idx = in ? (((uint32_t)cl(cz, nC) << (2 * C)) | ((uint32_t)cl(cy, nC) << C) | (uint32_t)cl(cx, nC)) : 0u;
     const bool occupied = in && ((cbits[idx >> 5] >> (idx & 31u)) & 1u);
     const bool clear = !occupied && ((ti + 0.5f * dt) * rad + 0.5f * dt <= 0.9f * cell);
     if (!clear) { j = l; break; }
@@ -167,8 +170,10 @@ template <typename VT> static float beam_start(const Octree<VT>& m, const std::v
       const float ti = t_safe + ((float)l + 0.5f) * dt2;
       const V3f p = org + dc * ti;
       const int cx = (int)floorf(p.x * inv_cellf), cy = (int)floorf(p.y * inv_cellf), cz = (int)floorf(p.z * inv_cellf);
-      const bool in = (uint32_t)(cx | cy | cz) < (1u << Fl);
-      const uint32_t idx = in ? (((uint32_t)cz << (2 * Fl)) | ((uint32_t)cy << Fl) | (uint32_t)cx) : 0u;
+      const int nF = 1 << Fl;
+      auto cl = [](int v, int n) { return std::min(std::max(v, 0), n - 1); };
+      const bool in = (uint32_t)(cx + 1) <= (uint32_t)nF && (uint32_t)(cy + 1) <= (uint32_t)nF && (uint32_t)(cz + 1) <= (uint32_t)nF;
+      const uint32_t idx = in ? (((uint32_t)cl(cz, nF) << (2 * Fl)) | ((uint32_t)cl(cy, nF) << Fl) | (uint32_t)cl(cx, nF)) : 0u;
       const bool occupied = in && (((*fbits)[idx >> 5] >> (idx & 31u)) & 1u);
       const bool clear = !occupied && ((ti + 0.5f * dt2) * rad + 0.5f * dt2 <= 0.9f * cellf);
       if (!clear) { j2 = l; break; }
@@ -189,7 +194,9 @@ template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm
   const int tiles_x = (p->W + 7) / 8, tiles_y = (p->H + 7) / 8;
   if (beam) {
     cbits = coarse_bits(oct, C);
-    const int Fl = oct.max_level_ - 3;
+    // the second stage's grid: level min(leaf, 6) (DevMap::flevel, se_device.h); bits 4.. of `beam` override it (experiments)
+    const int Fl = (beam >> 4) ? (beam >> 4) : std::min(oct.max_level_ - 3, 6);
+    beam &= 15;
     std::vector<uint32_t> fbits;
     if (beam >= 2 && Fl > C) fbits = coarse_bits(oct, Fl);
     tile_start.resize((size_t)tiles_x * tiles_y);
@@ -239,7 +246,7 @@ extern "C" void fl_debug(void* pipe, const float* pose_cm, const float* k, int x
   auto* p = dynamic_cast<Pipeline<SDFv>*>((PipelineBase*)pipe);
   const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
   const Octree<SDFv>& oct = p->oct;
-  const int C = std::min(oct.max_level_ - 3, 5), Fl = oct.max_level_ - 3;
+  const int C = std::min(oct.max_level_ - 3, 5), Fl = std::min(oct.max_level_ - 3, 6);
   auto cb = fl::coarse_bits(oct, C), fb = fl::coarse_bits(oct, Fl);
   const float ts = fl::beam_start(oct, cb, C, view, (x / 8) * 8, (y / 8) * 8, nearPlane, farPlane, beam >= 2 ? &fb : nullptr, Fl);
   const V3f dir = normalized(mul3(top3(view), {(float)x, (float)y, 1.f}));
