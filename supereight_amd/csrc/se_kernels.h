@@ -217,6 +217,7 @@ struct AllocArgs {
   int of_lvl[3];            // min(depth, leaf level) of the three stages (fetch_octant stops at the leaves) ...
   uint32_t of_off[3];       // ... and the offset of that level in the index pyramid (DevMap::off is never indexed dynamically on the device)
   int sharded;      // this replica scans only part of the image: report re-activated blocks to the peers
+  float* hint_out;  // the raycast's depth hint (RayArgs::hint): this scan's copy of the depth image; may be null
 };
 
 // ------------------------------------------------------------------------------------------
@@ -305,6 +306,7 @@ __device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __r
   }
   if (in_image) {
     const float depth = se_depth_at(ds, depthmap, x, y, a.W);
+    if (a.hint_out) a.hint_out[x + y * a.W] = depth;
     if (!(depth == 0)) {
       const f3 worldVertex = m34_mul_h(a.kpose, {(x + 0.5f) * depth, (y + 0.5f) * depth, depth});
       const f3 camera = {a.cam[0], a.cam[1], a.cam[2]};
@@ -364,6 +366,7 @@ __device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float*
     const int x = pid % a.W;
     const int y = a.row_begin + pid / a.W;
     const float depth = se_depth_at(ds, depthmap, x, y, a.W);
+    if (a.hint_out) a.hint_out[x + y * a.W] = depth;
     if (!(depth == 0)) {
       int tree_depth = m.max_level;
       float stepsize = a.voxel;
@@ -1091,6 +1094,10 @@ struct RayArgs {
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
                        // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
+  // Depth hint (r06; results do not depend on it): the depth image of the frame this raycast follows, copied by that frame's allocation scan -- for the pose
+  // it was integrated with, which is the raycast's in the reference's loop, the ray through pixel (x, y) meets the surface near t = depth(x, y) |view (x, y, 1)|.
+  // The march fetches the brick lines around that point while it is still two or three round trips away from them (se_prefetch_hit); null = off
+  const float* hint;
   unsigned long long* wlog;   // -DSE_WAVE_PROBE builds only (tools/wave_timeline.py): per-wave clock records, pinned host memory; null otherwise
 };
 
@@ -1570,20 +1577,12 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
   const uint32_t staged_parents = a.cache_codes >> 3;   // parents below this code have their sibling byte in LDS
   unsigned long long gp_bits = 0ull;   // the 64 leaf bits below the node two levels above the leaves the ray is in
   uint32_t gp_code = 0u;
-  // Volumes > 512^3 (r06): the sibling bytes of the parents one and two levels above the leaf parents (1024^3: level 5; 2048^3: levels 5 and 6) are not
-  // staged either, and r05 read each from global memory when its node was entered or popped back to -- a dependent round trip inside the trip, 0.6 us per
-  // trip for a wave alone on its SIMD against 0.26 us at 512^3, and the launch ends with rays of 55-60 trips (profiles/r06b_wave_timeline_sdf1024_closed.txt).
-  // They now come the way the leaf bits do: the 8 sibling bytes of a node's children are one aligned 8-byte group, fetched when the node is entered --
-  // a trip or more before the first child is -- and kept while the ray is below that node (a pop returns to a node the ray came down through).
-  unsigned long long g2_bits = 0ull, g3_bits = 0ull;   // groups of the nodes three / four levels above the leaves: the sibling bytes of their children
-  uint32_t g2_code = 0u, g3_code = 0u;
   before_loop();
-  // sibling byte of parent P, D levels above the leaf parents: staged -> LDS; from its parent's group; else global (never at <= 2048^3)
-#define SE_SIB_OF(P, D)                                                                                                                      \
-  ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)]                                                                                  \
-   : ((D) == 1 && ((P) >> 3) == g2_code) ? ((uint32_t)(g2_bits >> (((P) & 7u) << 3)) & 0xFFu)                                                 \
-   : ((D) == 2 && ((P) >> 3) == g3_code) ? ((uint32_t)(g3_bits >> (((P) & 7u) << 3)) & 0xFFu)                                                 \
-                                          : (uint32_t)occ_bytes[(P)])
+  // sibling byte of parent P: staged -> LDS; leaf parent -> byte (P & 7) of gp_bits; else (volumes > 512^3) global
+  // (r06, measured and dropped: fetching the 8 sibling bytes of a node's children as one 8-byte group when the node is entered, as the leaf bits are, so that
+  // neither a descent into a level-5 / level-6 node nor a pop back to one waits for memory inside the trip: k_raycast 67.2 -> 69.5 us at 1024^3, 205 -> 212 us
+  // at 2048^3 -- the load is needed one trip later, which a wave alone on its SIMD reaches long before the data; profiles/r06c_groups_ab.log)
+#define SE_SIB_OF(P) ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)] : (uint32_t)occ_bytes[(P)])
   uint32_t sib = s_occ8[1];   // the root's children: word 0 of the occupancy bits is always staged
   int guard = 0;
   const int max_trips = (!live || redo) ? 0 : 4096;
@@ -1610,11 +1609,8 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
         if ((parent >> 3) != gp_code) { gp_code = parent >> 3; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)gp_code << 3)); }
         sib = (uint32_t)(gp_bits >> ((parent & 7u) << 3)) & 0xFFu;
       } else {
-        const int dl = scale - a.min_scale;   // levels above the leaf parents
-        if (dl == 1) { gp_code = parent; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
-        else if (!SHALLOW && dl == 2 && !((parent << 3) < staged_parents)) { g2_code = parent; g2_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
-        else if (!SHALLOW && dl == 3 && !((parent << 3) < staged_parents)) { g3_code = parent; g3_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
-        sib = SE_SIB_OF(parent, dl);
+        if (scale == a.min_scale + 1) { gp_code = parent; gp_bits = *(const unsigned long long*)(occ_bytes + ((size_t)parent << 3)); }
+        sib = SE_SIB_OF(parent);
       }
     } else {
       // advance_ray (ray_iterator.hpp:116-167)
@@ -1634,7 +1630,7 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
           pos.x = __uint_as_float(__float_as_uint(pos.x) & keep);
           pos.y = __uint_as_float(__float_as_uint(pos.y) & keep);
           pos.z = __uint_as_float(__float_as_uint(pos.z) & keep);
-          sib = SE_SIB_OF(parent, scale - a.min_scale);
+          sib = SE_SIB_OF(parent);
         }
       }
     }
@@ -1815,17 +1811,47 @@ __device__ __forceinline__ SeSample<O32> se_sample_lean(const DevMap& m, const R
   s.vi = A::sum(A::tx(m, ux), A::ty(m, uy), A::tz(m, uz));
   return s;
 }
+// Depth-hint prefetch (r06).  From 1024^3 on the march is bound by the latency of cold brick lines: the sweep has just rewritten every visible brick, every
+// XCD's L2 starts the launch empty, and a ray's samples near the surface -- the last gets, their interpolation cells, the gradient stencil -- are a chain
+// of dependent round trips to lines nobody has touched yet (1.8 us per batch against 1.0 us at 512^3, profiles/r06b_wave_timeline_*).  Where those
+// samples will be is known up front to within a voxel (RayArgs::hint), so the lines around that point are requested when the march starts -- x plane,
+// z slices z-1 .. z+2 (the gradient's), and the y plane of slice z -- and are in L2 / L1 by the time the march gets there.  The values are never used:
+// the loads' results are kept alive (SE_PF_KEEP) until the entry interpolation has come back -- loads return in order, they have landed by then.
+#ifndef SE_PREFETCH
+#define SE_PREFETCH 1      // 0: off (A/B)
+#endif
+#define SE_PF_N 5
+template <bool O32>
+__device__ __forceinline__ void se_prefetch_hit(const DevMap& m, const RayArgs& a, f3 org, f3 dir, float t_hint, uint32_t pf[SE_PF_N]) {
+  typedef SeDense<O32> A;
+#pragma unroll
+  for (int k = 0; k < SE_PF_N; ++k) pf[k] = 0u;
+  if (!(t_hint > 0.f)) return;
+  const f3 q = f3_add(org, f3_scale_r(dir, t_hint));
+  const int ix = se_cvt_hw(a.inv_voxel * q.x), iy = se_cvt_hw(a.inv_voxel * q.y), iz = se_cvt_hw(a.inv_voxel * q.z);
+  if (!((uint32_t)(ix | iy | iz) < (uint32_t)m.size)) return;
+  const typename A::idx_t X = A::tx(m, (uint32_t)ix), Y = A::ty(m, (uint32_t)iy);
+  const int top = m.size - 1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pf[k] = __float_as_uint(A::ldx(m, A::sum(X, Y, A::tz(m, (uint32_t)min(max(iz + k - 1, 0), top)))));
+  pf[4] = __float_as_uint(A::ldy(m, A::sum(X, Y, A::tz(m, (uint32_t)iz))));
+}
+#define SE_PF_KEEP(pf) asm volatile("" ::"v"((pf)[0]), "v"((pf)[1]), "v"((pf)[2]), "v"((pf)[3]), "v"((pf)[4]))
+
 // raycast(const Volume<SDF>&, ...) (se_denseslam/src/kfusion/rendering_impl.hpp:34-74) on the dense grid; same float
 // operations in the same order as se_cast_ray's generic form below (which stays the path of pooled bricks)
 template <bool STATS, bool O32>
 __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
-                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc, float t_hint = 0.f) {
   typedef SeDense<O32> A;
   if (!(tnear < tfar)) return;
   float t = tnear;
   float stepsize = a.largestep;
   f3 position = f3_add(org, f3_scale_r(dir, t));
+  uint32_t pf[SE_PF_N];
+  if (SE_PREFETCH) se_prefetch_hit<O32>(m, a, org, dir, t_hint, pf);
   float f_t = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, position), c);
+  if (SE_PREFETCH) SE_PF_KEEP(pf);
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t > 0)) return;
@@ -2178,8 +2204,8 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
 
 template <bool OFUSION, bool STATS, bool DENSE, bool O32 = false>
 __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
-                                            BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
-  if (!OFUSION && DENSE) se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+                                            BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc, float t_hint = 0.f) {
+  if (!OFUSION && DENSE) se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc, t_hint);
   else if (OFUSION && DENSE) se_cast_ray_of_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
   else if (!OFUSION) se_cast_ray_sdf_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
   else se_cast_ray_of_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
@@ -2210,8 +2236,11 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
   const int cx = se_cvt_flr(p.x * a.beam_inv_cell), cy = se_cvt_flr(p.y * a.beam_inv_cell), cz = se_cvt_flr(p.z * a.beam_inv_cell);
   // A sample outside the volume sees no blocks -- unless it lies in the one-cell shell around it, within a cell of whatever is allocated on that face:
   // the shell takes the dilated bit of the boundary cell it touches (which covers every cell within one of the sample's own)
+#ifndef SE_BEAM_SHELL
+#define SE_BEAM_SHELL 1    // 0: samples outside the volume count as clear (the r05 form; A/B)
+#endif
   const int nC = 1 << C;
-  const bool in = (uint32_t)(cx + 1) <= (uint32_t)nC && (uint32_t)(cy + 1) <= (uint32_t)nC && (uint32_t)(cz + 1) <= (uint32_t)nC;
+  const bool in = SE_BEAM_SHELL ? ((uint32_t)(cx + 1) <= (uint32_t)nC && (uint32_t)(cy + 1) <= (uint32_t)nC && (uint32_t)(cz + 1) <= (uint32_t)nC) : ((uint32_t)(cx | cy | cz) < (uint32_t)nC);
   const uint32_t idx = in ? (((uint32_t)min(max(cz, 0), nC - 1) << (2 * C)) | ((uint32_t)min(max(cy, 0), nC - 1) << C) | (uint32_t)min(max(cx, 0), nC - 1)) : 0u;
   const uint32_t w = m.cbits[idx >> 5];
   const bool occupied = in && ((w >> (idx & 31u)) & 1u);
@@ -2228,7 +2257,7 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
     const int F = m.flevel;
     const int fx = se_cvt_flr(pf.x * a.beam_inv_cellf), fy = se_cvt_flr(pf.y * a.beam_inv_cellf), fz = se_cvt_flr(pf.z * a.beam_inv_cellf);
     const int nF = 1 << F;
-    const bool inf = (uint32_t)(fx + 1) <= (uint32_t)nF && (uint32_t)(fy + 1) <= (uint32_t)nF && (uint32_t)(fz + 1) <= (uint32_t)nF;   // (the shell: as above)
+    const bool inf = SE_BEAM_SHELL ? ((uint32_t)(fx + 1) <= (uint32_t)nF && (uint32_t)(fy + 1) <= (uint32_t)nF && (uint32_t)(fz + 1) <= (uint32_t)nF) : ((uint32_t)(fx | fy | fz) < (uint32_t)nF);   // (the shell: as above)
     const uint32_t fidx = inf ? (((uint32_t)min(max(fz, 0), nF - 1) << (2 * F)) | ((uint32_t)min(max(fy, 0), nF - 1) << F) | (uint32_t)min(max(fx, 0), nF - 1)) : 0u;
     const uint32_t fw = m.fbits[fidx >> 5];
     const bool clear2 = !(inf && ((fw >> (fidx & 31u)) & 1u)) && ((tf + 0.5f * a.beam_dt2) * rad + 0.5f * a.beam_dt2 <= 0.9f * a.beam_cellf);
@@ -2306,8 +2335,12 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
   }
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
   const bool in_image = px < a.W && py < a.row_end;
-  const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
+  const f3 vdir = m3_mul(a.view3, {(float)px, (float)py, 1.f});
+  const f3 dir = f3_normalized(vdir);
   const f3 org = {a.org[0], a.org[1], a.org[2]};
+  // depth hint of this pixel (issued with the staging loads, first used behind the first-leaf search)
+  float hint_depth = 0.f;
+  if (SE_PREFETCH && DENSE && !OFUSION && a.hint && in_image) hint_depth = a.hint[px + py * a.W];
   auto finish_staging = [&]() {
 #pragma unroll
     for (int j = 0; j < kStage; ++j) { const int i = threadIdx.x + j * SE_WG_RAY; if (i < a.cache_words) s_occ[i] = st[j]; }
@@ -2333,7 +2366,8 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     BlkCache c = {-1, -1, -1, 0u};
     if (t_min > 0.f) {
       RayCounters rc = {0ull, 0ull, 0u};
-      se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
+      const float t_hint = (SE_PREFETCH && DENSE && !OFUSION) ? hint_depth * sqrtf(f3_sqnorm(vdir)) : 0.f;
+      se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc, t_hint);
       if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
       my_cost = (unsigned)SE_COST_BATCH * rc.n_batch;
     }

@@ -30,6 +30,7 @@
 namespace fl {
 
 struct Result { float t_min; int found; int flagged; int irregular; int trips; };
+static thread_local int* g_adv_hist = nullptr;   // (experiments: advances per scale, descents at [32 + scale])
 
 // the node whose children are the cells of `scale`, found from pos alone (what `code >> 3 * levels` is on the device)
 template <typename VT> static Node<VT>* node_at(const Octree<VT>& m, V3f pos, int scale, int om) {
@@ -82,6 +83,7 @@ template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f d
       if (tc_max < t_min) { r.flagged = 1; break; }
       const float half = scale_exp2 * 0.5f;
       const V3f t_center = half * tc + t_corner;
+      if (g_adv_hist) ++g_adv_hist[32 + scale];
       parent = child;
       --scale;
       scale_exp2 = half;
@@ -91,6 +93,7 @@ template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f d
       continue;
     }
     // advance_ray without idx_: "leaves the parent" = a bit above `scale` changed
+    if (g_adv_hist) ++g_adv_hist[scale];
     const V3f old = pos;
     if (t_corner.x <= tc_max) pos.x -= scale_exp2;
     if (t_corner.y <= tc_max) pos.y -= scale_exp2;
@@ -242,6 +245,33 @@ extern "C" void fl_compare(void* pipe, const float* pose_cm, const float* k, int
 }
 
 // debug: one pixel
+// experiments: trips of every ray (lite, with the beam start) and, summed over the rays with >= min_trips trips, advances per scale [0..31] / descents [32..63]
+extern "C" void fl_trip_map(void* pipe, const float* pose_cm, const float* k, int beam, int min_trips, int32_t* trips, int64_t* hist) {
+  auto* p = dynamic_cast<Pipeline<SDFv>*>((PipelineBase*)pipe);
+  const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
+  const Octree<SDFv>& oct = p->oct;
+  const int C = std::min(oct.max_level_ - 3, 5), Fl = std::min(oct.max_level_ - 3, 6);
+  auto cb = fl::coarse_bits(oct, C);
+  std::vector<uint32_t> fb;
+  if (beam >= 2 && Fl > C) fb = fl::coarse_bits(oct, Fl);
+  const int tiles_x = (p->W + 7) / 8, tiles_y = (p->H + 7) / 8;
+  std::vector<float> ts((size_t)tiles_x * tiles_y, 0.f);
+  if (beam)
+    for (int ty = 0; ty < tiles_y; ++ty)
+      for (int tx = 0; tx < tiles_x; ++tx) ts[(size_t)ty * tiles_x + tx] = fl::beam_start(oct, cb, C, view, tx * 8, ty * 8, nearPlane, farPlane, fb.empty() ? nullptr : &fb, Fl);
+  for (int i = 0; i < 64; ++i) hist[i] = 0;
+  for (int y = 0; y < p->H; ++y)
+    for (int x = 0; x < p->W; ++x) {
+      const V3f dir = normalized(mul3(top3(view), {(float)x, (float)y, 1.f}));
+      const V3f transl = {view.m[0][3], view.m[1][3], view.m[2][3]};
+      int h[64] = {0};
+      fl::g_adv_hist = h;
+      const fl::Result r = fl::lite(oct, transl, dir, nearPlane, farPlane, ts[(size_t)(y / 8) * tiles_x + x / 8]);
+      fl::g_adv_hist = nullptr;
+      trips[(size_t)y * p->W + x] = r.trips;
+      if (r.trips >= min_trips) for (int i = 0; i < 64; ++i) hist[i] += h[i];
+    }
+}
 extern "C" void fl_debug(void* pipe, const float* pose_cm, const float* k, int x, int y, int beam, double* out) {
   auto* p = dynamic_cast<Pipeline<SDFv>*>((PipelineBase*)pipe);
   const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
