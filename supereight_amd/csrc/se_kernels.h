@@ -1666,6 +1666,9 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 #define SE_MARCH_SKIP 4    // SDF march in unobserved space: positions asked of the leaf bitmap per round trip (se_march_skip); 0 = off.  Measured 0 / 4 / 8
                            // (profiles/r04p_march_skip_ab.log): 59.8 / 59.8 / 61.6 us per frame at 512^3, 193.8 / 188.4 / 189.5 at 1024^3, stress 69.7 / 68.6 / 71.3
 #endif
+#ifndef SE_MARCH_EXTRAPOLATE
+#define SE_MARCH_EXTRAPOLATE 1   // SDF march inside the band: the speculative second sample continues the geometric sequence of the steps (se_cast_ray_sdf_lean); 0 = off (A/B)
+#endif
 #ifndef SE_MARCH_PROBE
 #define SE_MARCH_PROBE 1   // dense maps > 512^3: leaf-bitmap probe in front of brick reads while the march is in unobserved space (se_cast_ray_sdf_lean)
 #endif
@@ -1855,7 +1858,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t > 0)) return;
-  float S = a.largestep;
+  float S = a.largestep, S_prev = 0.f;   // the last two steps taken
   bool done = false;
   // (r05, measured and dropped: 4 samples per round trip instead of 2 from the 3rd / 6th batch of a ray on, outside the truncation band -- aimed at the
   // silhouette rays whose 12-23 round trips end the launch: fused launch 43.2 / 41.8 instead of 35.8 us at 512^3, 75 / 73 instead of 71 us at 1024^3,
@@ -1872,7 +1875,15 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
       if (!(t < tfar)) break;
     }
     const f3 q0 = position;
-    const f3 q1 = f3_add(q0, f3_scale(S, dir));
+    // The second sample of a batch is a guess at where the march will be after the first: one step of the size just taken.  In free space (f = 1: steps
+    // of mu), in unobserved space (largestep) and at the minimum step that is exact and the sample is consumed.  Inside the truncation band of a surface
+    // met at a shallow angle it never is: the step is the distance to the surface, which shrinks by the same factor from sample to sample (a ray at 10
+    // degrees to a wall takes 16 samples from the band's edge to the surface) -- each lands in another brick, 10-20 voxels on, on lines nobody has touched,
+    // and those rays end the launch (profiles/r06d_wave_timeline_sdf1024_closed.txt: 14-16 batches of 1.8 us in the last waves at 1024^3).  There the guess
+    // continues the geometric sequence, S * (S / S_prev): it is still never the exact position, but it is within a voxel or two of it -- its loads are the
+    // prefetch of the next sample's lines (r06; results cannot depend on it: a guess is consumed only if it equals the step taken, bit for bit).
+    const float S1 = (SE_MARCH_EXTRAPOLATE && band && S < S_prev) ? S * (S / S_prev) : S;
+    const f3 q1 = f3_add(q0, f3_scale(S1, dir));
     SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
     float x0, y0, x1, y1;
     bool probed = false;
@@ -1892,6 +1903,8 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
      }
     }
     if (!probed) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
+    float x1z = 0.f;   // (extrapolated guess: the next z slice of its voxel too -- the interpolation cell of the sample it stands in for spans two slices)
+    if (SE_MARCH_EXTRAPOLATE >= 2 && S1 != S) { const SeSample<O32> s1z = se_sample_lean<O32>(m, a, {q1.x, q1.y, q1.z + a.step}); x1z = A::ldx(m, s1z.vi); }
     SeCell<O32> cell0;
     float cv0[8];
     bool have0 = false;
@@ -1903,6 +1916,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
         for (int k = 0; k < 8; ++k) cv0[k] = A::ldx(m, cell0.vi[k]);
       }
     }
+    if (SE_MARCH_EXTRAPOLATE >= 2) asm volatile("" ::"v"(x1z));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (!(t < tfar)) { done = true; break; }
@@ -1933,7 +1947,8 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
         band = f_tt < 1.f;
       }
       t += stepsize;
-      if (stepsize != S) { S = stepsize; break; }
+      S_prev = S; S = stepsize;
+      if (stepsize != S1) break;
     }
   }
   if (f_tt < 0) {
@@ -1982,8 +1997,8 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t > 0)) return;
-  float S = a.largestep;
-  bool done = false, unobs = false;
+  float S = a.largestep, S_prev = 0.f;
+  bool done = false, unobs = false, band = f_t < 1.f;
   SePCache pc = {0xFFFFFFFFu, 0u};
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
     ++rc.n_batch;
@@ -1992,7 +2007,8 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
       if (!(t < tfar)) break;
     }
     const f3 q0 = position;
-    const f3 q1 = f3_add(q0, f3_scale(S, dir));
+    const float S1 = (SE_MARCH_EXTRAPOLATE && band && S < S_prev) ? S * (S / S_prev) : S;   // (see se_cast_ray_sdf_lean)
+    const f3 q1 = f3_add(q0, f3_scale(S1, dir));
     const SePSample s0 = se_sample_pooled<true>(m, a, q0, pc, unobs), s1 = se_sample_pooled<true>(m, a, q1, pc, unobs);
     const size_t i0 = se_pooled_index(s0), i1 = se_pooled_index(s1);
     const float x0 = m.vx[i0], y0 = m.vx[i0 + 512], x1 = m.vx[i1], y1 = m.vx[i1 + 512];
@@ -2006,6 +2022,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
       if (dy == 0) {
         stepsize = a.largestep;
         position = f3_add(position, f3_scale(stepsize, dir));
+        band = false;
       } else {
         f_tt = dx;
         if (f_tt < 0.1f && f_tt >= -0.5f) {   // (double)f_tt <= 0.1
@@ -2017,9 +2034,11 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
         stepsize = fmaxf(f_tt * a.mu, a.step);
         position = f3_add(position, f3_scale(stepsize, dir));
         f_t = f_tt;
+        band = f_tt < 1.f;
       }
       t += stepsize;
-      if (stepsize != S) { S = stepsize; break; }
+      S_prev = S; S = stepsize;
+      if (stepsize != S1) break;
     }
   }
   if (f_tt < 0) {
