@@ -1582,7 +1582,16 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
   // (r06, measured and dropped: fetching the 8 sibling bytes of a node's children as one 8-byte group when the node is entered, as the leaf bits are, so that
   // neither a descent into a level-5 / level-6 node nor a pop back to one waits for memory inside the trip: k_raycast 67.2 -> 69.5 us at 1024^3, 205 -> 212 us
   // at 2048^3 -- the load is needed one trip later, which a wave alone on its SIMD reaches long before the data; profiles/r06c_groups_ab.log)
-#define SE_SIB_OF(P) ((SHALLOW || (P) < staged_parents) ? (uint32_t)s_occ8[(P)] : (uint32_t)occ_bytes[(P)])
+  // (r06: written as a branch with the LDS value pinned.  As `staged ? s_occ8[P] : occ_bytes[P]` the compiler loads ONCE from a selected address -- a FLAT
+  // load, which counts on both memory counters: every trip of the > 512^3 instantiations then began with s_waitcnt vmcnt(0) lgkmcnt(0), i.e. waited for the
+  // leaf-bit group it had issued a trip ahead as well, and a staged byte cost a flat round trip instead of an LDS read: 0.53 us per trip for a wave alone on
+  // its SIMD at 1024^3 against 0.26 us at 512^3, profiles/r06b_wave_timeline_sdf1024_closed.txt)
+  // (the global arm is a wavefront-scope relaxed atomic load -- an ordinary load to the hardware, but one the compiler cannot fold into the LDS read)
+  auto sib_of = [&](uint32_t P) -> uint32_t {
+    if (SHALLOW || P < staged_parents) return (uint32_t)s_occ8[P];
+    return (uint32_t)__hip_atomic_load(occ_bytes + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  };
+#define SE_SIB_OF(P) sib_of(P)
   uint32_t sib = s_occ8[1];   // the root's children: word 0 of the occupancy bits is always staged
   int guard = 0;
   const int max_trips = (!live || redo) ? 0 : 4096;
