@@ -20,9 +20,10 @@
  *   - one handle <-> one caller thread at a time (the reference is not re-entrant either).
  *   - all work is enqueued on one HIP stream per handle; calls that return data to the host
  *     synchronise that stream, the others are asynchronous -- with one exception (the "host gate", dense unsharded
- *     handles): se_hip_alloc_scan / se_hip_integrate / se_hip_frame and the depth uploads wait on the HOST until the
+ *     handles): se_hip_alloc_scan / se_hip_integrate / se_hip_frame wait on the HOST until the
  *     raycast behind the previous integration sweep has started on the device (normally less than a frame period; after
- *     20 ms of wall clock the wait turns into hipStreamSynchronize of the handle's stream).  A caller that hands in its own
+ *     20 ms of wall clock the wait turns into hipStreamSynchronize of the handle's stream); a depth upload waits the same way for the raycast
+ *     behind the sweep of three uploads ago (the slot it overwrites).  A caller that hands in its own
  *     stream (se_hip_set_stream) must therefore not hold that stream behind work it has not enqueued yet.  SE_HIP_HOST_GATE=0
  *     in the environment selects the event-ordered form, in which no stage call waits on the host.
  *   - SE_HIP_E_CAPACITY is sticky: once a pool, key list or brick segment has overflowed, every later stage call and
@@ -109,7 +110,10 @@ int se_hip_scan_overlaps(se_hip_pipeline* p);
  *   - se_hip_vertex_normal_device on a streaming handle WITHOUT an image ring switches deferral off for good (sticky): raw pointers and deferral
  *     never coexist;
  *   - with an image ring (below) the contract is explicit: slot (f % slots) holds frame f's images once the NEXT se_hip_frame / se_hip_integrate
- *     call (or any flushing call) has returned and the handle's stream has reached that point.
+ *     call (or any flushing call) has returned and the handle's stream has reached that point;
+ *   - a caller that turns out to look at every frame -- the reference's loop with tracking on: se_hip_track(f+1) needs raycasting(f)'s images -- gains
+ *     nothing from holding raycasts back (they start later and fuse with no scan).  After two held-back raycasts in a row that some other call had
+ *     to launch, with no fused launch in between, the handle launches raycasts eagerly again (r06; se_hip_set_streaming(p, 1) re-arms deferral).
  * Handles whose raycast fits the chip in one round of workgroups (640x480: 2 400 of 2 560) fuse; others (statistics on, sharded sweep, larger
  * images) keep the eager two-queue schedule whatever the flag says.  Row-sharded replicas and handles with a caller key buffer or an exchange fuse
  * too: the scan half of the launch writes the caller's list on the MAIN stream, and se_hip_alloc_exchange / se_hip_alloc_commit follow it there
@@ -126,10 +130,16 @@ int se_hip_frame_is_fused(se_hip_pipeline* p);
 int se_hip_set_image_ring(se_hip_pipeline* p, float* device_ring, int32_t slots);
 
 /* ---- input: float_depth_ (se::Image<float>, metres, row-major x + y*w), produced by
- * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141). */
+ * preprocessing() in the reference (DenseSLAMSystem.cpp:128-141).
+ * Host images (r06): the call copies the caller's buffer into a ring of three pinned host buffers and returns -- like the reference's synchronous
+ * preprocessing(), the caller may reuse its buffer at once -- and enqueues NOTHING: the first kernel of the frame that needs float_depth_ (the allocation
+ * scan, one thread per pixel; or a one-kernel conversion in front of se_hip_track / se_hip_render_depth / a row-sharded scan) reads the pinned image over
+ * PCIe and writes the device image on its way.  No DMA packet, no second queue, no wait for the previous frame: on a streaming handle the input of frame
+ * f+1 crosses PCIe inside the launch that raycasts frame f.  The call waits (on the host) only if all three slots are still in flight, i.e. if the caller
+ * is three uploads ahead of the device. */
 int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m);
-/* mm2metersKernel fused into the upload (se_denseslam/src/preprocessing.cpp:161-188):
- * uint16 millimetres of size (in_w, in_h), an integer multiple of the computation size. */
+/* mm2metersKernel (se_denseslam/src/preprocessing.cpp:161-188) applied where the image is first read on the device:
+ * uint16 millimetres of size (in_w, in_h), an integer multiple of the computation size ("Invalid ratio." = SE_HIP_E_INVALID). */
 int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_depth_mm, int32_t in_w, int32_t in_h);
 /* Zero-copy: integrate from a depth image already resident in HBM (width*height floats).  The buffer is read by the
  * allocation scan and by the integration sweep of the frame: it must stay untouched until that sweep has finished

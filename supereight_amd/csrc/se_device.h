@@ -50,10 +50,9 @@ struct DevMap {
                                   // within one coarse cell of any point of this cell.  Only ever set (never cleared: blocks are never freed).  The second
                                   // half of the allocation holds the same grid undilated ("a block exists in this cell": se_mark_coarse).
   int clevel;
-  uint32_t* fbits;                // the same on a finer grid, level flevel = min(leaf_level, 6) (7.5 cm cells at 4.8 m: the margin an 8x8-pixel beam of a 640x480 camera
+  uint32_t* fbits;                // the same on a finer grid, level se_flevel(m) = min(leaf_level, 6) (7.5 cm cells at 4.8 m: the margin an 8x8-pixel beam of a 640x480 camera
                                   // needs at working distance; r05 used the block grid itself, whose margin at 1024^3 -- 3.75 cm -- the beam does not fit): set for every cell
-                                  // within one cell of an allocated block; 32 KB (second stage of the beam start, OFusion leap); null if flevel <= clevel
-  int flevel;
+                                  // within one cell of an allocated block; 32 KB (second stage of the beam start, OFusion leap); null if that level is <= clevel
   int size, max_level, leaf_level;
   int defer_occ;                  // 1: insertions do not touch occ[] (a commit kernel sets the bits later)
   int defer_mark;                 // 1: insertions do not mark cbits / fbits (se_occ_commit does, from the key list, before the next raycast: every allocation scan)
@@ -165,6 +164,9 @@ __device__ __forceinline__ void occ_set(const DevMap& m, int l, int x, int y, in
   const uint32_t code = occ_code(l, x, y, z);
   atomicOr(&m.occ[code >> 5], 1u << (code & 31u));
 }
+// level of the fbits grid (derived, not stored: the raycast kernels run at the scalar-register limit)
+#define SE_FLEVEL_MAX 6
+__host__ __device__ __forceinline__ int se_flevel(const DevMap& m) { return m.leaf_level < SE_FLEVEL_MAX ? m.leaf_level : SE_FLEVEL_MAX; }
 __device__ __forceinline__ bool in_volume(const DevMap& m, int x, int y, int z) {
   return (unsigned)x < (unsigned)m.size && (unsigned)y < (unsigned)m.size && (unsigned)z < (unsigned)m.size;
 }

@@ -182,12 +182,6 @@ struct se_hip_pipeline {
   bool in_event[kIn] = {false, false, false};
   int cur_in = -1;                          // ring slot p->depth points into (-1: the caller's device image)
   DepthSrc in_pending{nullptr, nullptr, 0, 0, 0};   // host-resident input not yet materialised on the device
-  // depth hint of the raycast (RayArgs::hint): every allocation scan leaves a copy of its depth image in one of two buffers (alternating: the scan of frame
-  // f+1 writes one while the raycast of frame f, in the same fused launch, reads the other); a raycast with that scan's pose and intrinsics uses it
-  float* hint_buf[2] = {nullptr, nullptr};
-  int hint_next = 0, hint_last = -1;
-  float hint_pose[16] = {0}, hint_k[4] = {0};
-  bool prefetch = true;          // SE_HIP_PREFETCH=0 switches the hint off (A/B knob: results are the same either way)
   float* vertex = nullptr;       // vertex_ / normal_ as every consumer (tracking, rendering, the getters) sees them: the images of the LAST raycast
   float* normal = nullptr;       // launched -- the handle's own buffers, or the slot of the image ring that raycast wrote
   float* vertex_own = nullptr;
@@ -339,7 +333,7 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.ray_order = p->ray_order; a.n_cus = p->n_cus;
   // beam start: 64 samples on a tile's centre ray, half a coarse cell apart (or whatever spacing covers near .. far)
   a.beam = (p->beam >= 2 && !m.fbits) ? 1 : p->beam;
-  const int flevel = m.fbits ? m.flevel : m.leaf_level;   // (no fbits: leaf_level <= clevel, the coarse grid is the block grid)
+  const int flevel = m.fbits ? se_flevel(m) : m.leaf_level;   // (no fbits: leaf_level <= clevel, the coarse grid is the block grid)
   a.beam_cellf = m.dim / (float)(1 << flevel);
   a.beam_inv_cellf = (float)(1 << flevel) / m.dim;
   a.beam_dt2 = 0.4f * a.beam_cellf;
@@ -358,8 +352,6 @@ RayLaunchArgs make_ray_args(se_hip_pipeline* p, const float pose_cm[16], const f
   a.leap_bits = !p->of_leap ? nullptr : m.fbits ? m.fbits : (m.clevel == m.leaf_level ? m.cbits : nullptr);
   a.leap_level = flevel;
   a.leap_dt = 0.9f * a.beam_cellf;
-  a.hint = (p->prefetch && p->hint_last >= 0 && std::memcmp(pose_cm, p->hint_pose, sizeof p->hint_pose) == 0 && std::memcmp(k, p->hint_k, sizeof p->hint_k) == 0)
-               ? p->hint_buf[p->hint_last] : nullptr;
   a.wlog = nullptr;
 #ifdef SE_WAVE_PROBE
   {
@@ -544,7 +536,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (const char* ev = std::getenv("SE_HIP_INTEG_GRID")) p->integ_grid = std::atoi(ev);            // tuning knob
   if (const char* ev = std::getenv("SE_HIP_BEAM")) p->beam = std::max(0, std::min(2, std::atoi(ev)));   // A/B + test knob
   if (const char* ev = std::getenv("SE_HIP_OF_LEAP")) p->of_leap = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SE_HIP_PREFETCH")) p->prefetch = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SE_HIP_IEEE_SWEEP")) p->ieee_sweep = std::atoi(ev) != 0;       // A/B + test knob: the sweep instantiation with the compiler's divisions
   if (const char* ev = std::getenv("SE_HIP_PRIO")) p->prio_hint = std::atoi(ev) != 0;              // tuning knob
   if (const char* ev = std::getenv("SE_HIP_PRIO_SHARE")) {                                         // tuning knob
@@ -621,8 +612,8 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   p->cbits_words = std::max<size_t>(1, ((size_t)1 << (3 * m.clevel)) / 32);
   ALLOC(m.cbits, 2 * p->cbits_words * sizeof(uint32_t));   // [dilated bits][undilated bits of the same grid: se_mark_coarse]
   m.fbits = nullptr;
-  m.flevel = std::min(p->leaf_level, 6);      // cells of dim / 64 (7.5 cm at 4.8 m): second stage of the beam start, OFusion leap
-  if (m.flevel > m.clevel) { p->fbits_words = ((size_t)1 << (3 * m.flevel)) / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
+  // the level-min(leaf, 6) grid, cells of dim / 64 (7.5 cm at 4.8 m): second stage of the beam start, OFusion leap
+  if (se_flevel(m) > m.clevel) { p->fbits_words = ((size_t)1 << (3 * se_flevel(m))) / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
   m.vy = m.vx + 512;
   ALLOC(m.bpos, cap * sizeof(uint32_t));
@@ -640,7 +631,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   ALLOC(p->vertex_own, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   ALLOC(p->normal_own, (size_t)cfg->width * cfg->height * 3 * sizeof(float));
   p->vertex = p->vertex_own; p->normal = p->normal_own;
-  for (int i = 0; i < 2; ++i) { ALLOC(p->hint_buf[i], (size_t)cfg->width * cfg->height * sizeof(float)); hipMemsetAsync(p->hint_buf[i], 0, (size_t)cfg->width * cfg->height * sizeof(float), p->stream); }
   ALLOC(p->chain, 4 * sizeof(unsigned long long));
   const size_t n_tiles = ((size_t)(cfg->width + SE_TILE_W - 1) / SE_TILE_W) * ((size_t)(cfg->height + SE_TILE_H - 1) / SE_TILE_H);
   ALLOC(p->tile_cost, (n_tiles + 4096) * sizeof(unsigned short));   // (+ padding: se_ray_schedule reads it in 16-byte pieces)
@@ -694,7 +684,7 @@ int se_hip_destroy(se_hip_pipeline* p) {
   for (auto& ev : p->event_pool) hipEventDestroy(ev);
   DevMap& m = p->map;
   void* ptrs[] = {m.occ, m.lbits, m.cbits, m.fbits, m.tab, m.vx, m.bpos, m.bactive, m.nx, m.ny, m.npos, m.nlevel, m.ctr, m.stats, p->newkeys_own, p->newkeys_own2,
-                  p->depth_ring[0], p->depth_ring[1], p->depth_ring[2], p->hint_buf[0], p->hint_buf[1], p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
+                  p->depth_ring[0], p->depth_ring[1], p->depth_ring[2], p->vertex_own, p->normal_own, p->bspline, p->logodds, p->chain, p->tile_cost, p->prio_thr, p->ray_order};
   for (void* q : ptrs) if (q) hipFree(q);
   for (auto* q : p->pyr_depth) if (q) hipFree(q);
   for (auto* q : p->pyr_vertex) if (q) hipFree(q);
@@ -955,7 +945,6 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
   }
   const int npix = (p->row_end - p->row_begin) * p->cfg.width;
   const dim3 grid((npix + SE_WG_SCAN - 1) / SE_WG_SCAN), block(SE_WG_SCAN);
-  a.hint_out = p->hint_buf[p->hint_next];
   // an input image still in host memory: this scan visits every pixel once and materialises float_depth_ on its way (DepthSrc); a row-sharded replica's
   // scan sees only its own rows, the sweep behind it needs all of them
   if (a.sharded) materialise_depth(p, s);
@@ -972,7 +961,6 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
     const int scan_wgs = sdf ? (sdf_tiles + SE_WG_SCAN / 64 - 1) / (SE_WG_SCAN / 64) : (int)grid.x;
     if (int r = launch_raycast_scan(p, ms, a, scan_wgs, ds)) return r;
     input_slot_in_use(p);
-    p->hint_last = p->hint_next; p->hint_next ^= 1; std::memcpy(p->hint_pose, pose_cm, sizeof p->hint_pose); std::memcpy(p->hint_k, k, sizeof p->hint_k);
     p->occ_commit_due = true;
     if (!p->occ_lists.lists) p->occ_lists = OccLists{p->map.newkeys, 1, (long long)p->map.cap_keys + 1};
     if (!sdf && !a.sharded) { if (int r = run_zero_chain(p, p->map.newkeys, 1, (long long)p->map.cap_keys + 1)) return r; }   // (sharded: se_hip_alloc_commit, over every rank's list)
@@ -996,7 +984,6 @@ int se_hip_alloc_scan(se_hip_pipeline* p, const float pose_cm[16], const float k
     }
   }
   input_slot_in_use(p);
-  p->hint_last = p->hint_next; p->hint_next ^= 1; std::memcpy(p->hint_pose, pose_cm, sizeof p->hint_pose); std::memcpy(p->hint_k, k, sizeof p->hint_k);
   if (ov) {
     HIP_TRY(hipEventRecord(p->ev_scan, p->side));
     p->scan_pending = true;

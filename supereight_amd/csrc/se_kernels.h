@@ -115,7 +115,7 @@ __device__ __forceinline__ void se_mark_coarse(const DevMap& m, int bx, int by, 
     atomicOr(cown + (idx >> 5), bit);
     se_mark_dilated(m.cbits, C, cx, cy, cz);
   }
-  if (m.fbits) { const int fs = m.leaf_level - m.flevel; se_mark_dilated(m.fbits, m.flevel, bx >> fs, by >> fs, bz >> fs); }
+  if (m.fbits) { const int fl = se_flevel(m), fs = m.leaf_level - fl; se_mark_dilated(m.fbits, fl, bx >> fs, by >> fs, bz >> fs); }
 }
 
 // `want` = false: the lane only accompanies the others of its wave (shared counter updates, se_wave_take); the callers pass the lanes that found the
@@ -217,7 +217,6 @@ struct AllocArgs {
   int of_lvl[3];            // min(depth, leaf level) of the three stages (fetch_octant stops at the leaves) ...
   uint32_t of_off[3];       // ... and the offset of that level in the index pyramid (DevMap::off is never indexed dynamically on the device)
   int sharded;      // this replica scans only part of the image: report re-activated blocks to the peers
-  float* hint_out;  // the raycast's depth hint (RayArgs::hint): this scan's copy of the depth image; may be null
 };
 
 // ------------------------------------------------------------------------------------------
@@ -306,7 +305,6 @@ __device__ __forceinline__ void se_scan_sdf_wg(const DevMap& m, const float* __r
   }
   if (in_image) {
     const float depth = se_depth_at(ds, depthmap, x, y, a.W);
-    if (a.hint_out) a.hint_out[x + y * a.W] = depth;
     if (!(depth == 0)) {
       const f3 worldVertex = m34_mul_h(a.kpose, {(x + 0.5f) * depth, (y + 0.5f) * depth, depth});
       const f3 camera = {a.cam[0], a.cam[1], a.cam[2]};
@@ -366,7 +364,6 @@ __device__ __forceinline__ void se_scan_ofusion_wg(const DevMap& m, const float*
     const int x = pid % a.W;
     const int y = a.row_begin + pid / a.W;
     const float depth = se_depth_at(ds, depthmap, x, y, a.W);
-    if (a.hint_out) a.hint_out[x + y * a.W] = depth;
     if (!(depth == 0)) {
       int tree_depth = m.max_level;
       float stepsize = a.voxel;
@@ -1094,10 +1091,6 @@ struct RayArgs {
   int cost_shift;      // tile costs are stored >> cost_shift so that the 256 bins of se_ray_schedule keep their resolution in volumes
                        // > 512^3, whose traversals are 2-4x as long (costs beyond 255 all fell into the last bin)
   const int* prio_thr; // cost thresholds of s_setprio 1 / 2 / 3, refreshed by the integration sweep (se_ray_schedule)
-  // Depth hint (r06; results do not depend on it): the depth image of the frame this raycast follows, copied by that frame's allocation scan -- for the pose
-  // it was integrated with, which is the raycast's in the reference's loop, the ray through pixel (x, y) meets the surface near t = depth(x, y) |view (x, y, 1)|.
-  // The march fetches the brick lines around that point while it is still two or three round trips away from them (se_prefetch_hit); null = off
-  const float* hint;
   unsigned long long* wlog;   // -DSE_WAVE_PROBE builds only (tools/wave_timeline.py): per-wave clock records, pinned host memory; null otherwise
 };
 
@@ -1582,14 +1575,16 @@ __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const Ray
   // (r06, measured and dropped: fetching the 8 sibling bytes of a node's children as one 8-byte group when the node is entered, as the leaf bits are, so that
   // neither a descent into a level-5 / level-6 node nor a pop back to one waits for memory inside the trip: k_raycast 67.2 -> 69.5 us at 1024^3, 205 -> 212 us
   // at 2048^3 -- the load is needed one trip later, which a wave alone on its SIMD reaches long before the data; profiles/r06c_groups_ab.log)
-  // (r06: written as a branch with the LDS value pinned.  As `staged ? s_occ8[P] : occ_bytes[P]` the compiler loads ONCE from a selected address -- a FLAT
-  // load, which counts on both memory counters: every trip of the > 512^3 instantiations then began with s_waitcnt vmcnt(0) lgkmcnt(0), i.e. waited for the
-  // leaf-bit group it had issued a trip ahead as well, and a staged byte cost a flat round trip instead of an LDS read: 0.53 us per trip for a wave alone on
-  // its SIMD at 1024^3 against 0.26 us at 512^3, profiles/r06b_wave_timeline_sdf1024_closed.txt)
-  // (the global arm is a wavefront-scope relaxed atomic load -- an ordinary load to the hardware, but one the compiler cannot fold into the LDS read)
+  // (r06, measured: for the > 512^3 instantiations the compiler turns this select of two loads into ONE load of a selected address -- a FLAT load, which counts
+  // on both memory counters, so every trip begins with s_waitcnt vmcnt(0) lgkmcnt(0).  Forcing two loads -- the LDS value pinned by an empty asm, or the global
+  // arm as a wavefront-scope atomic load (SE_SIB_SPLIT) -- was slower, not faster: k_raycast 68.4 -> 70.0 us at 1024^3, the last waves' search phase 36 -> 40 us,
+  // because the pinned LDS read is waited for at once instead of at the top of the next trip; profiles/r06f_flatfix_ab.log)
+#ifndef SE_SIB_SPLIT
+#define SE_SIB_SPLIT 0
+#endif
   auto sib_of = [&](uint32_t P) -> uint32_t {
-    if (SHALLOW || P < staged_parents) return (uint32_t)s_occ8[P];
-    return (uint32_t)__hip_atomic_load(occ_bytes + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (SE_SIB_SPLIT && !SHALLOW && !(P < staged_parents)) return (uint32_t)__hip_atomic_load(occ_bytes + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return (SHALLOW || P < staged_parents) ? (uint32_t)s_occ8[P] : (uint32_t)occ_bytes[P];
   };
 #define SE_SIB_OF(P) sib_of(P)
   uint32_t sib = s_occ8[1];   // the root's children: word 0 of the occupancy bits is always staged
@@ -1675,8 +1670,8 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 #define SE_MARCH_SKIP 4    // SDF march in unobserved space: positions asked of the leaf bitmap per round trip (se_march_skip); 0 = off.  Measured 0 / 4 / 8
                            // (profiles/r04p_march_skip_ab.log): 59.8 / 59.8 / 61.6 us per frame at 512^3, 193.8 / 188.4 / 189.5 at 1024^3, stress 69.7 / 68.6 / 71.3
 #endif
-#ifndef SE_MARCH_EXTRAPOLATE
-#define SE_MARCH_EXTRAPOLATE 1   // SDF march inside the band: the speculative second sample continues the geometric sequence of the steps (se_cast_ray_sdf_lean); 0 = off (A/B)
+#ifndef SE_POOLED_CELL
+#define SE_POOLED_CELL 1   // pooled SDF march: the interpolation cell of sample 0 fetched with the batch when it lies inside the sample's brick; 0 = off (A/B)
 #endif
 #ifndef SE_MARCH_PROBE
 #define SE_MARCH_PROBE 1   // dense maps > 512^3: leaf-bitmap probe in front of brick reads while the march is in unobserved space (se_cast_ray_sdf_lean)
@@ -1823,51 +1818,21 @@ __device__ __forceinline__ SeSample<O32> se_sample_lean(const DevMap& m, const R
   s.vi = A::sum(A::tx(m, ux), A::ty(m, uy), A::tz(m, uz));
   return s;
 }
-// Depth-hint prefetch (r06).  From 1024^3 on the march is bound by the latency of cold brick lines: the sweep has just rewritten every visible brick, every
-// XCD's L2 starts the launch empty, and a ray's samples near the surface -- the last gets, their interpolation cells, the gradient stencil -- are a chain
-// of dependent round trips to lines nobody has touched yet (1.8 us per batch against 1.0 us at 512^3, profiles/r06b_wave_timeline_*).  Where those
-// samples will be is known up front to within a voxel (RayArgs::hint), so the lines around that point are requested when the march starts -- x plane,
-// z slices z-1 .. z+2 (the gradient's), and the y plane of slice z -- and are in L2 / L1 by the time the march gets there.  The values are never used:
-// the loads' results are kept alive (SE_PF_KEEP) until the entry interpolation has come back -- loads return in order, they have landed by then.
-#ifndef SE_PREFETCH
-#define SE_PREFETCH 1      // 0: off (A/B)
-#endif
-#define SE_PF_N 5
-template <bool O32>
-__device__ __forceinline__ void se_prefetch_hit(const DevMap& m, const RayArgs& a, f3 org, f3 dir, float t_hint, uint32_t pf[SE_PF_N]) {
-  typedef SeDense<O32> A;
-#pragma unroll
-  for (int k = 0; k < SE_PF_N; ++k) pf[k] = 0u;
-  if (!(t_hint > 0.f)) return;
-  const f3 q = f3_add(org, f3_scale_r(dir, t_hint));
-  const int ix = se_cvt_hw(a.inv_voxel * q.x), iy = se_cvt_hw(a.inv_voxel * q.y), iz = se_cvt_hw(a.inv_voxel * q.z);
-  if (!((uint32_t)(ix | iy | iz) < (uint32_t)m.size)) return;
-  const typename A::idx_t X = A::tx(m, (uint32_t)ix), Y = A::ty(m, (uint32_t)iy);
-  const int top = m.size - 1;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) pf[k] = __float_as_uint(A::ldx(m, A::sum(X, Y, A::tz(m, (uint32_t)min(max(iz + k - 1, 0), top)))));
-  pf[4] = __float_as_uint(A::ldy(m, A::sum(X, Y, A::tz(m, (uint32_t)iz))));
-}
-#define SE_PF_KEEP(pf) asm volatile("" ::"v"((pf)[0]), "v"((pf)[1]), "v"((pf)[2]), "v"((pf)[3]), "v"((pf)[4]))
-
 // raycast(const Volume<SDF>&, ...) (se_denseslam/src/kfusion/rendering_impl.hpp:34-74) on the dense grid; same float
 // operations in the same order as se_cast_ray's generic form below (which stays the path of pooled bricks)
 template <bool STATS, bool O32>
 __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
-                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc, float t_hint = 0.f) {
+                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
   typedef SeDense<O32> A;
   if (!(tnear < tfar)) return;
   float t = tnear;
   float stepsize = a.largestep;
   f3 position = f3_add(org, f3_scale_r(dir, t));
-  uint32_t pf[SE_PF_N];
-  if (SE_PREFETCH) se_prefetch_hit<O32>(m, a, org, dir, t_hint, pf);
   float f_t = se_interp_lean<O32>(m, fc, f3_scale(a.inv_voxel, position), c);
-  if (SE_PREFETCH) SE_PF_KEEP(pf);
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t > 0)) return;
-  float S = a.largestep, S_prev = 0.f;   // the last two steps taken
+  float S = a.largestep;
   bool done = false;
   // (r05, measured and dropped: 4 samples per round trip instead of 2 from the 3rd / 6th batch of a ray on, outside the truncation band -- aimed at the
   // silhouette rays whose 12-23 round trips end the launch: fused launch 43.2 / 41.8 instead of 35.8 us at 512^3, 75 / 73 instead of 71 us at 1024^3,
@@ -1884,15 +1849,13 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
       if (!(t < tfar)) break;
     }
     const f3 q0 = position;
-    // The second sample of a batch is a guess at where the march will be after the first: one step of the size just taken.  In free space (f = 1: steps
-    // of mu), in unobserved space (largestep) and at the minimum step that is exact and the sample is consumed.  Inside the truncation band of a surface
-    // met at a shallow angle it never is: the step is the distance to the surface, which shrinks by the same factor from sample to sample (a ray at 10
-    // degrees to a wall takes 16 samples from the band's edge to the surface) -- each lands in another brick, 10-20 voxels on, on lines nobody has touched,
-    // and those rays end the launch (profiles/r06d_wave_timeline_sdf1024_closed.txt: 14-16 batches of 1.8 us in the last waves at 1024^3).  There the guess
-    // continues the geometric sequence, S * (S / S_prev): it is still never the exact position, but it is within a voxel or two of it -- its loads are the
-    // prefetch of the next sample's lines (r06; results cannot depend on it: a guess is consumed only if it equals the step taken, bit for bit).
-    const float S1 = (SE_MARCH_EXTRAPOLATE && band && S < S_prev) ? S * (S / S_prev) : S;
-    const f3 q1 = f3_add(q0, f3_scale(S1, dir));
+    // (r06, measured and dropped: inside the truncation band of a surface met at a shallow angle the step shrinks by a constant factor from sample to sample --
+    // a ray at 10 degrees to a wall takes ~16 samples from the band's edge to the surface, and those rays end the launch -- so the speculative second sample
+    // was placed at S * (S / S_prev), within a voxel or two of the next position, as a prefetch of its lines: +-0 at 512^3 / 1024^3 / 2048^3, with or without
+    // the next z slice of its voxel, profiles/r06e_extrapolate_ab.log.  Likewise a prefetch of the brick lines around the depth image's own estimate of the
+    // hit point, issued when the march starts: +-0, profiles/r06d_prefetch_ab.log.  A batch of those rays is two dependent round trips and ~400 instructions
+    // of a wave alone on its SIMD whatever the cache state.)
+    const f3 q1 = f3_add(q0, f3_scale(S, dir));
     SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
     float x0, y0, x1, y1;
     bool probed = false;
@@ -1912,8 +1875,6 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
      }
     }
     if (!probed) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
-    float x1z = 0.f;   // (extrapolated guess: the next z slice of its voxel too -- the interpolation cell of the sample it stands in for spans two slices)
-    if (SE_MARCH_EXTRAPOLATE >= 2 && S1 != S) { const SeSample<O32> s1z = se_sample_lean<O32>(m, a, {q1.x, q1.y, q1.z + a.step}); x1z = A::ldx(m, s1z.vi); }
     SeCell<O32> cell0;
     float cv0[8];
     bool have0 = false;
@@ -1925,7 +1886,6 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
         for (int k = 0; k < 8; ++k) cv0[k] = A::ldx(m, cell0.vi[k]);
       }
     }
-    if (SE_MARCH_EXTRAPOLATE >= 2) asm volatile("" ::"v"(x1z));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (!(t < tfar)) { done = true; break; }
@@ -1956,8 +1916,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
         band = f_tt < 1.f;
       }
       t += stepsize;
-      S_prev = S; S = stepsize;
-      if (stepsize != S1) break;
+      if (stepsize != S) { S = stepsize; break; }
     }
   }
   if (f_tt < 0) {
@@ -2006,7 +1965,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
   if (STATS) ++rc.n_interp;
   float f_tt = 0;
   if (!(f_t > 0)) return;
-  float S = a.largestep, S_prev = 0.f;
+  float S = a.largestep;
   bool done = false, unobs = false, band = f_t < 1.f;
   SePCache pc = {0xFFFFFFFFu, 0u};
   for (int guard = 0; t < tfar && !done && guard < 65536; ++guard) {
@@ -2016,11 +1975,27 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
       if (!(t < tfar)) break;
     }
     const f3 q0 = position;
-    const float S1 = (SE_MARCH_EXTRAPOLATE && band && S < S_prev) ? S * (S / S_prev) : S;   // (see se_cast_ray_sdf_lean)
-    const f3 q1 = f3_add(q0, f3_scale(S1, dir));
+    const f3 q1 = f3_add(q0, f3_scale(S, dir));
     const SePSample s0 = se_sample_pooled<true>(m, a, q0, pc, unobs), s1 = se_sample_pooled<true>(m, a, q1, pc, unobs);
     const size_t i0 = se_pooled_index(s0), i1 = se_pooled_index(s1);
     const float x0 = m.vx[i0], y0 = m.vx[i0 + 512], x1 = m.vx[i1], y1 = m.vx[i1 + 512];
+    // (r06) inside the truncation band the interpolation cell of sample 0 rides with the batch, as on the dense grid -- when the cell lies inside sample 0's
+    // own brick (no corner on another block: two cells in three), its eight addresses follow from the entry the sample has just looked up.  Same values,
+    // same blend as se_interp_generic; one round trip instead of two for the sample that decides the step
+    bool have0 = false;
+    float cv0[8], cfx = 0.f, cfy = 0.f, cfz = 0.f;
+    if (SE_POOLED_CELL && band && s0.e) {
+      const f3 pv = f3_scale(a.inv_voxel, q0);
+      const float flx = floorf(pv.x), fly = floorf(pv.y), flz = floorf(pv.z);
+      const int lx = max(cvt_i32(flx), 0), ly = max(cvt_i32(fly), 0), lz = max(cvt_i32(flz), 0);
+      if ((lx & 7) != 7 && (ly & 7) != 7 && (lz & 7) != 7 && (lx >> 3) == s0.bx && (ly >> 3) == s0.by && (lz >> 3) == s0.bz) {
+        have0 = true;
+        cfx = pv.x - flx; cfy = pv.y - fly; cfz = pv.z - flz;
+        const size_t base = ((size_t)(s0.e - 1u) << 10) + (size_t)((lx & 7) + ((ly & 7) << 3) + ((lz & 7) << 6));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv0[k] = m.vx[base + (size_t)((k & 1) + ((k >> 1) & 1) * 8 + (k >> 2) * 64)];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (!(t < tfar)) { done = true; break; }
@@ -2035,8 +2010,13 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
       } else {
         f_tt = dx;
         if (f_tt < 0.1f && f_tt >= -0.5f) {   // (double)f_tt <= 0.1
-          c.bx = sm.bx; c.by = sm.by; c.bz = sm.bz; c.e = sm.e;      // the block of this sample as the look-up hint
-          f_tt = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, position), c);
+          if (i == 0 && have0) {
+            f_tt = (((cv0[0] * (1 - cfx) + cv0[1] * cfx) * (1 - cfy) + (cv0[2] * (1 - cfx) + cv0[3] * cfx) * cfy) * (1 - cfz) +
+                    ((cv0[4] * (1 - cfx) + cv0[5] * cfx) * (1 - cfy) + (cv0[6] * (1 - cfx) + cv0[7] * cfx) * cfy) * cfz);
+          } else {
+            c.bx = sm.bx; c.by = sm.by; c.bz = sm.bz; c.e = sm.e;      // the block of this sample as the look-up hint
+            f_tt = se_interp_generic<false>(m, fc, f3_scale(a.inv_voxel, position), c);
+          }
           if (STATS) ++rc.n_interp;
         }
         if (f_tt < 0) { done = true; break; }
@@ -2046,8 +2026,7 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
         band = f_tt < 1.f;
       }
       t += stepsize;
-      S_prev = S; S = stepsize;
-      if (stepsize != S1) break;
+      if (stepsize != S) { S = stepsize; break; }
     }
   }
   if (f_tt < 0) {
@@ -2232,8 +2211,8 @@ __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayAr
 
 template <bool OFUSION, bool STATS, bool DENSE, bool O32 = false>
 __device__ __forceinline__ void se_cast_ray(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float t_min, float tfar,
-                                            BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc, float t_hint = 0.f) {
-  if (!OFUSION && DENSE) se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc, t_hint);
+                                            BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
+  if (!OFUSION && DENSE) se_cast_ray_sdf_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
   else if (OFUSION && DENSE) se_cast_ray_of_lean<STATS, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
   else if (!OFUSION) se_cast_ray_sdf_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
   else se_cast_ray_of_pooled<STATS>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
@@ -2282,7 +2261,7 @@ __device__ __forceinline__ float se_beam_start(const DevMap& m, const RayArgs& a
     const float t1 = fmaxf(t_safe, a.nearp);
     const float tf = t1 + ((float)lane + 0.5f) * a.beam_dt2;
     const f3 pf = f3_add(org, f3_scale_r(dc, tf));
-    const int F = m.flevel;
+    const int F = se_flevel(m);
     const int fx = se_cvt_flr(pf.x * a.beam_inv_cellf), fy = se_cvt_flr(pf.y * a.beam_inv_cellf), fz = se_cvt_flr(pf.z * a.beam_inv_cellf);
     const int nF = 1 << F;
     const bool inf = SE_BEAM_SHELL ? ((uint32_t)(fx + 1) <= (uint32_t)nF && (uint32_t)(fy + 1) <= (uint32_t)nF && (uint32_t)(fz + 1) <= (uint32_t)nF) : ((uint32_t)(fx | fy | fz) < (uint32_t)nF);   // (the shell: as above)
@@ -2363,12 +2342,8 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
   }
   unsigned long long n_get = 0, n_interp = 0, n_grad = 0, n_hit = 0;
   const bool in_image = px < a.W && py < a.row_end;
-  const f3 vdir = m3_mul(a.view3, {(float)px, (float)py, 1.f});
-  const f3 dir = f3_normalized(vdir);
+  const f3 dir = f3_normalized(m3_mul(a.view3, {(float)px, (float)py, 1.f}));
   const f3 org = {a.org[0], a.org[1], a.org[2]};
-  // depth hint of this pixel (issued with the staging loads, first used behind the first-leaf search)
-  float hint_depth = 0.f;
-  if (SE_PREFETCH && DENSE && !OFUSION && a.hint && in_image) hint_depth = a.hint[px + py * a.W];
   auto finish_staging = [&]() {
 #pragma unroll
     for (int j = 0; j < kStage; ++j) { const int i = threadIdx.x + j * SE_WG_RAY; if (i < a.cache_words) s_occ[i] = st[j]; }
@@ -2394,8 +2369,7 @@ __device__ __forceinline__ void se_raycast_wg(const DevMap& m, const RayArgs& a,
     BlkCache c = {-1, -1, -1, 0u};
     if (t_min > 0.f) {
       RayCounters rc = {0ull, 0ull, 0u};
-      const float t_hint = (SE_PREFETCH && DENSE && !OFUSION) ? hint_depth * sqrtf(f3_sqnorm(vdir)) : 0.f;
-      se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc, t_hint);
+      se_cast_ray<OFUSION, STATS, DENSE, O32>(m, a, fc, org, dir, t_min, tfar, c, hx, hy, hz, hw, rc);
       if (STATS) { n_get += rc.n_get; n_interp += rc.n_interp; }
       my_cost = (unsigned)SE_COST_BATCH * rc.n_batch;
     }
