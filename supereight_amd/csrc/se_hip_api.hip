@@ -5,9 +5,6 @@
 #include "../../include/se_hip.h"
 
 #include <hip/hip_runtime.h>
-#if defined(__x86_64__)
-#include <emmintrin.h>
-#endif
 
 #include <algorithm>
 #include <cmath>
@@ -559,12 +556,14 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   // Pooled mode (max_blocks > 0, or a grid that does not fit): max_blocks bricks behind the index.
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  // r04: a dense grid is the default only while it costs <= SE_HIP_DENSE_MAX_GIB (see below).  Beyond that (2048^3: 64 GiB for a ~2 GB payload) the
-  // default is the pooled layout.  Its default capacity follows what a scan can allocate -- surfaces, not volume: four layers of blocks on each of the
-  // six faces of the volume's cube, 24 (N/8)^2 bricks (1.5 GiB at 1024^3, 6 GiB at 2048^3; 4-5x what the benchmark streams allocate there), at least
-  // 65 536; a pool that runs out is reported (SE_HIP_E_CAPACITY), max_blocks raises it.  Measured with the lean pooled march
-  // (profiles/r04h_pooled_vs_dense.log, two queues): pooled is 2.6 % / 3.0 % behind dense in frames/s at 1024^3 / 2048^3 and 25 % behind at 512^3.
-  size_t dense_max_gib = 16;
+  // A dense grid is the default while it costs <= SE_HIP_DENSE_MAX_GIB and a third of what is free.  r04-r05 drew the line at 16 GiB (2048^3 = 64 GiB for a
+  // ~2 GB payload went pooled: "2.6 % / 3.0 % behind dense", profiles/r04h_pooled_vs_dense.log).  r06, measured again on the current kernels, same box
+  // (profiles/r06h_dense2048_ab.log, r06a_dense_sdf2048_pmc_summary.md): at 1280x960 -> 2048^3 the dense raycast is 215 us beside the scan against 286 us
+  // (163 / 203 us stand-alone), the scan 226 against 308 us, the sweep 738 against 702 us (bricks one 4 KB page each: 74 k address-translation misses per
+  // launch against 2.5 k) -- 1 010 against 956 frames/s: a 288 GB part has the 64 GiB, so the line is 64 GiB now.  The pooled layout's default capacity
+  // follows what a scan can allocate -- surfaces, not volume: four layers of blocks on each of the six faces of the volume's cube, 24 (N/8)^2 bricks
+  // (1.5 GiB at 1024^3, 6 GiB at 2048^3), at least 65 536; a pool that runs out is reported (SE_HIP_E_CAPACITY), max_blocks raises it.
+  size_t dense_max_gib = 64;
   if (const char* ev = std::getenv("SE_HIP_DENSE_MAX_GIB")) dense_max_gib = (size_t)std::max(0, std::atoi(ev));
   bool dense = cfg->max_blocks <= 0 && cells * 4096 <= free_b / 3 && cells * 4096 <= (dense_max_gib << 30);
   if (const char* ev = std::getenv("SE_HIP_DENSE")) dense = std::atoi(ev) != 0 && cells * 4096 <= free_b / 2;
@@ -758,27 +757,6 @@ int se_hip_set_scan_stream(se_hip_pipeline* p, void* hip_stream) {
   return SE_HIP_OK;
 }
 
-// The caller's image -> a pinned slot.  The device reads the slot over PCIe exactly once and the CPU never again: streaming (non-temporal) stores keep the
-// 0.6-1.2 MB out of the CPU's caches -- no read-for-ownership of the destination lines, and the device's reads are served by memory instead of by snoops
-// of dirty lines (x86-64; elsewhere memcpy).
-static void copy_to_pinned(void* dst, const void* src, size_t bytes) {
-#if defined(__x86_64__)
-  if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0 && bytes >= 4096) {
-    const __m128i* s = (const __m128i*)src;
-    __m128i* d = (__m128i*)dst;
-    const size_t n = bytes / 64;
-    for (size_t i = 0; i < n; ++i) {
-      const __m128i a = _mm_load_si128(s + 4 * i), b = _mm_load_si128(s + 4 * i + 1), c = _mm_load_si128(s + 4 * i + 2), e = _mm_load_si128(s + 4 * i + 3);
-      _mm_stream_si128(d + 4 * i, a); _mm_stream_si128(d + 4 * i + 1, b); _mm_stream_si128(d + 4 * i + 2, c); _mm_stream_si128(d + 4 * i + 3, e);
-    }
-    _mm_sfence();
-    if (bytes & 63) std::memcpy((char*)dst + n * 64, (const char*)src + n * 64, bytes & 63);
-    return;
-  }
-#endif
-  std::memcpy(dst, src, bytes);
-}
-
 // Host image -> the next slot of the pinned input ring (see se_hip_pipeline::in_host); nothing is enqueued.
 static int stage_input(se_hip_pipeline* p, const void* host, size_t bytes, int kind, int in_w, int ratio) {
   constexpr int R = se_hip_pipeline::kIn;
@@ -806,7 +784,7 @@ static int stage_input(se_hip_pipeline* p, const void* host, size_t bytes, int k
     HIP_TRY(hipStreamSynchronize(p->stream));
   }
   p->in_state[i] = 0; p->in_event[i] = false;
-  copy_to_pinned(p->in_host[i], host, bytes);
+  std::memcpy(p->in_host[i], host, bytes);   // (r06, measured: non-temporal stores here took 21 us instead of 16 us for the 614 KB image and moved nothing on the device side)
   p->in_pending = DepthSrc{p->in_host[i], p->depth_ring[i], kind, in_w, ratio};
   p->depth = p->depth_ring[i];
   p->cur_in = i;
@@ -1787,7 +1765,7 @@ int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float*
   auto slot_of = [&](size_t i) -> size_t {
     if (!p->map.dense) return i;
     const uint32_t bp = pos[i];
-    return ((((size_t)(bp >> 20) << L) | ((bp >> 10) & 1023u)) << L) | (bp & 1023u);
+    return (size_t)se_blk_term(bp & 1023u, 0, L) + (size_t)se_blk_term((bp >> 10) & 1023u, 1, L) + (size_t)se_blk_term(bp >> 20, 2, L);   // block_linear of a dense map
   };
   std::vector<uint8_t> act_all(p->slots);
   HIP_TRY(hipMemcpy(act_all.data(), p->map.bactive, p->slots, hipMemcpyDeviceToHost));

@@ -85,13 +85,15 @@ def test_640x480_512_properties(field, mu, frames):
     p.close(); q.close()
 
 
-def test_1280x960_2048_full_size_oracle_parity():
+@pytest.mark.parametrize("max_blocks", [0, 1 << 20], ids=["dense-64GiB", "pooled"])
+def test_1280x960_2048_full_size_oracle_parity(max_blocks):
     """BASELINE.json configs[3] at its FULL size against the oracle (parity had only been run at 160x120 -> 2048^3):
     1280x960 -> 2048^3, frames 0..3 -- 402 k blocks allocated by frame 0, one raycast (frame 3) -- in the default layout of that size
-    (pooled bricks).  Block / node sets, every voxel, active flags, hit mask, vertices and normals bit for bit.  ~20 s of oracle."""
+    (r06: the dense 64 GiB brick grid where the device has the memory) and in pooled bricks.  Block / node sets, every voxel, active flags,
+    hit mask, vertices and normals bit for bit.  ~20 s of oracle each."""
     from tests.parity_util import compare_maps, compare_raycast, run_both
     W, H, N, dim, mu, frames = 1280, 960, 2048, 4.8, 0.1, 4
-    cpu, gpu, recs = run_both(SDF, W, H, N, dim, mu, frames)
+    cpu, gpu, recs = run_both(SDF, W, H, N, dim, mu, frames, max_blocks=max_blocks)
     m = compare_maps(cpu, gpu)
     assert m["same_block_set"] and m["same_node_set"] and m["blocks_cpu"] > 350_000, m
     assert m["x_mismatch"] == 0 and m["y_mismatch"] == 0 and m["active_mismatch"] == 0 and m["node_x_mismatch"] == 0 and m["node_y_mismatch"] == 0, m
