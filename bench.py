@@ -514,6 +514,7 @@ def main():
     timings = sp.p.timings(reset=True) if not args.no_events else None
     sp.p.enable_timing(False)
     nblocks, nnodes = sp.p.counts()
+    mem = sp.p.memory_info()
     sp.close()
     if scratch is not None:
         scratch.close()
@@ -536,6 +537,8 @@ def main():
                                     else "two queues: scan(f+1) on a side stream beside raycast(f), event wait in front of sweep(f+1)"),
                        "parallelism": "single replica" if world == 1 else f"image rows sharded over {world} ranks, map replicated, RCCL all-gather of new-block key lists" + (", sweep sharded by block owner + RCCL all-gather of the updated bricks" if sp.shard_sweep else ""),
                        "blocks_allocated": nblocks, "nodes_allocated": nnodes,
+                       "memory_per_replica": {"layout": mem["layout"], "voxel_bricks_GiB": round(mem["brick_bytes"] / 2**30, 3), "device_GiB": round(mem["device_bytes"] / 2**30, 3),
+                                              "payload_GiB": round(nblocks * 4096 / 2**30, 3)},
                        "prewarm": f"{prewarm_frames} untimed frames on a scratch map before the W warm-up frames (clocks / caches warm, see bench.py prewarm()); "
                                   "gc.collect() + gc.freeze() before the warm-up frames (the interpreter's full collection over the import-time heap otherwise "
                                   "lands inside the first loop: profiles/r04f_stall_attribution.md)"},

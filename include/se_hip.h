@@ -62,7 +62,7 @@ typedef struct se_hip_config {
   float volume_dimension;    /* metres per side */
   int32_t field_type;        /* SE_HIP_FIELD_* */
   int32_t device;            /* HIP device ordinal */
-  int64_t max_blocks;        /* capacity of the voxel-block pool; 0 = default (a dense brick grid while it costs <= 16 GiB, else 24 (N/8)^2 pooled bricks) */
+  int64_t max_blocks;        /* capacity of the voxel-block pool; 0 = default (a dense brick grid while it costs <= 64 GiB and a third of the free device memory, else 24 (N/8)^2 pooled bricks) */
   int32_t row_begin;         /* image rows [row_begin,row_end) this handle alloc-scans and */
   int32_t row_end;           /*   raycasts (multi-GPU tile sharding); 0,0 = the whole image */
 } se_hip_config;
@@ -279,6 +279,10 @@ int se_hip_render_track(se_hip_pipeline* p, uint8_t* host_rgbw);
 /* ---- map read-back: what getMap() exposes as a host se::Octree
  *      (DenseSLAMSystem.h:295; se_core/include/se/octree.hpp:898-914 save layout). */
 int se_hip_counts(se_hip_pipeline* p, int32_t* n_blocks, int32_t* n_nodes);
+/* What the map costs on the device (no reference counterpart: MemoryPool grows on the host heap, se_core/include/se/utils/memory_pool.hpp:64-95):
+ * out[0] = 1 dense brick grid / 0 pooled bricks, out[1] = brick slots, out[2] = bytes of the voxel bricks, out[3] = bytes of everything the handle
+ * holds on the device (bricks, index pyramid, bitmaps, lists, key buffers, images, input ring).  Does not touch the device. */
+int se_hip_memory_info(se_hip_pipeline* p, int64_t out[4]);
 /* blocks sorted by key: coords[n][3] (min corner, voxels), x[n][512], y[n][512] (voxel index
  * x + 8y + 64z, se_core/include/se/node.hpp:139-144), active[n] */
 int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float* y, uint8_t* active);

@@ -133,23 +133,11 @@ __device__ __forceinline__ uint32_t pack_pos(int x, int y, int z) { return (uint
 __device__ __forceinline__ uint32_t tab_index(const DevMap& m, int l, int x, int y, int z) {
   return m.off[l] + (((((uint32_t)z << l) | (uint32_t)y) << l) | (uint32_t)x);
 }
-// Order of the dense brick grid (r06): tiles of 8 x 8 x 8 blocks -- a tile's 512 bricks are 2 MiB of consecutive memory -- instead of rows of the whole
-// grid.  A surface that crosses a tile touches ~64 of its bricks; in row-major order the same 2 MiB were two 4.8 m long, one-block-thin rows of the
-// volume, which a surface crosses in one or two bricks: every brick of a sweep or a march was its own large page and its own DRAM row (74 k
-// address-translation misses per sweep at 2048^3 against 2.5 k for pooled bricks, profiles/r06a_dense_sdf2048_pmc_summary.md).  The index stays a sum of
-// one term per axis (what the lean march and the stencils build their addresses from): se_blk_term(b, axis) of the block coordinate b.
-#ifndef SE_DENSE_TILED
-#define SE_DENSE_TILED 1
-#endif
-__host__ __device__ __forceinline__ uint32_t se_blk_term(uint32_t b, int axis, int leaf_level) {
-  if (!SE_DENSE_TILED) return b << (axis * leaf_level);
-  return ((b >> 3) << (9 + axis * (leaf_level - 3))) | ((b & 7u) << (3 * axis));      // (leaf_level >= 3: volumes of at least 64^3)
-}
-// index of block (bx, by, bz) in block-grid order: dense bricks (= their voxel slot), active flags and the leaf bitmap of a dense map use the tiled
-// order; pooled maps keep rows (their leaf bitmap shares its index with the leaf level of tab[])
+// (r06, measured and dropped: ordering the dense brick grid in tiles of 8 x 8 x 8 blocks -- 2 MiB of consecutive bricks per tile -- instead of rows of the
+// whole grid, so that the bricks a surface patch touches share large pages and DRAM rows: the sweep at 2048^3 stayed at 745 us, the scan lost 10 % to the
+// index conversion, 512^3 lost 2 % to the longer per-axis terms of the march; profiles/r06i_tiled_ab.log)
 __device__ __forceinline__ uint32_t block_linear(const DevMap& m, int bx, int by, int bz) {
   const int l = m.leaf_level;
-  if (m.dense) return se_blk_term((uint32_t)bx, 0, l) + se_blk_term((uint32_t)by, 1, l) + se_blk_term((uint32_t)bz, 2, l);
   return ((((uint32_t)bz << l) | (uint32_t)by) << l) | (uint32_t)bx;
 }
 // voxel slot of the block at list position `idx` with packed position `bp`

@@ -1746,6 +1746,17 @@ int se_hip_dump_mesh(se_hip_pipeline* p, const char* filename) {
   return SE_HIP_OK;
 }
 
+int se_hip_memory_info(se_hip_pipeline* p, int64_t out[4]) {
+  if (!p || !out) return fail(SE_HIP_E_INVALID, "bad argument");
+  const DevMap& m = p->map;
+  const size_t px = (size_t)p->cfg.width * p->cfg.height;
+  const size_t bricks = p->slots * 1024 * sizeof(float);
+  size_t all = bricks + p->tab_entries * 4 + (p->occ_words + p->lbits_words + 2 * p->cbits_words + p->fbits_words) * 4 + p->cap_blocks * 4 + ((p->slots + 3) & ~(size_t)3) +
+               p->cap_nodes * (2 * 8 * 4 + 4 + 1) + 2 * (m.cap_keys + 1) * 8 + se_hip_pipeline::kIn * px * 4 + 2 * px * 3 * 4;
+  out[0] = m.dense ? 1 : 0; out[1] = (int64_t)p->slots; out[2] = (int64_t)bricks; out[3] = (int64_t)all;
+  return SE_HIP_OK;
+}
+
 int se_hip_counts(se_hip_pipeline* p, int32_t* nb, int32_t* nn) {
   if (int r = check(p)) return r;
   if (int r = fetch_counters(p)) return r;
@@ -1765,7 +1776,7 @@ int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float*
   auto slot_of = [&](size_t i) -> size_t {
     if (!p->map.dense) return i;
     const uint32_t bp = pos[i];
-    return (size_t)se_blk_term(bp & 1023u, 0, L) + (size_t)se_blk_term((bp >> 10) & 1023u, 1, L) + (size_t)se_blk_term(bp >> 20, 2, L);   // block_linear of a dense map
+    return ((((size_t)(bp >> 20) << L) | ((bp >> 10) & 1023u)) << L) | (bp & 1023u);
   };
   std::vector<uint8_t> act_all(p->slots);
   HIP_TRY(hipMemcpy(act_all.data(), p->map.bactive, p->slots, hipMemcpyDeviceToHost));

@@ -247,8 +247,7 @@ __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& 
 #pragma unroll
   for (int k = 0; k < SE_SCAN_SLOTS; ++k) {
     const uint32_t l = k < nb ? lin[k] : lin[0];
-    // dense: active flag (at the block's voxel slot: the tiled order of block_linear; `lin` itself is in rows, the order of tab[]); pooled: index entry
-    val[k] = DENSE ? (uint32_t)m.bactive[block_linear(m, (int)(l & mask), (int)((l >> L) & mask), (int)(l >> (2 * L)))] : m.tab[m.leaf_off + l];
+    val[k] = DENSE ? (uint32_t)m.bactive[l] : m.tab[m.leaf_off + l];   // dense: active flag; pooled: index entry
   }
 #pragma unroll
   for (int k = 0; k < SE_SCAN_SLOTS; ++k) {
@@ -1198,9 +1197,9 @@ __device__ __forceinline__ float se_interp_generic(const DevMap& m, const FieldC
 // computation per sample (the gradient's 32 samples were a quarter of the kernel's vector instructions).
 // Same loads, same arithmetic on the values as the generic forms, which stay the fallback.
 struct AxisTerm { uint32_t blk, loc; };
-__device__ __forceinline__ AxisTerm se_axis_x(const DevMap& m, int x) { return {se_blk_term((uint32_t)(x >> 3), 0, m.leaf_level), (uint32_t)(x & 7)}; }
-__device__ __forceinline__ AxisTerm se_axis_y(const DevMap& m, int y) { return {se_blk_term((uint32_t)(y >> 3), 1, m.leaf_level), (uint32_t)(y & 7) << 3}; }
-__device__ __forceinline__ AxisTerm se_axis_z(const DevMap& m, int z) { return {se_blk_term((uint32_t)(z >> 3), 2, m.leaf_level), (uint32_t)(z & 7) << 6}; }
+__device__ __forceinline__ AxisTerm se_axis_x(int x) { return {(uint32_t)(x >> 3), (uint32_t)(x & 7)}; }
+__device__ __forceinline__ AxisTerm se_axis_y(const DevMap& m, int y) { return {(uint32_t)(y >> 3) << m.leaf_level, (uint32_t)(y & 7) << 3}; }
+__device__ __forceinline__ AxisTerm se_axis_z(const DevMap& m, int z) { return {(uint32_t)(z >> 3) << (2 * m.leaf_level), (uint32_t)(z & 7) << 6}; }
 __device__ __forceinline__ size_t se_axis_index(AxisTerm a, AxisTerm b, AxisTerm c) {
   return (size_t)(a.blk + b.blk + c.blk) * SE_BRICK_STRIDE + (size_t)(a.loc + b.loc + c.loc);
 }
@@ -1222,7 +1221,7 @@ __device__ __forceinline__ InterpCell se_interp_cell_dense(const DevMap& m, cons
   const int nb = m.size >> 3;
   const int top = m.size - 1;
   if (lx < top && ly < top && lz < top) {   // the whole cell inside the volume: per-axis terms (see se_axis_index)
-    const AxisTerm X[2] = {se_axis_x(m, lx), se_axis_x(m, lx + 1)}, Y[2] = {se_axis_y(m, ly), se_axis_y(m, ly + 1)}, Z[2] = {se_axis_z(m, lz), se_axis_z(m, lz + 1)};
+    const AxisTerm X[2] = {se_axis_x(lx), se_axis_x(lx + 1)}, Y[2] = {se_axis_y(m, ly), se_axis_y(m, ly + 1)}, Z[2] = {se_axis_z(m, lz), se_axis_z(m, lz + 1)};
 #pragma unroll
     for (int k = 0; k < 8; ++k) vi[k] = se_axis_index(X[k & 1], Y[(k >> 1) & 1], Z[k >> 2]);
     cell.ok = 0xFFu;
@@ -1325,7 +1324,7 @@ __device__ __forceinline__ float se_interp(const DevMap& m, const FieldConst fc,
   const int top = m.size - 1;
   if (!(lx < top && ly < top && lz < top)) return se_interp_generic<DENSE>(m, fc, pos, c);   // a corner outside the volume
   const float fx = pos.x - flx, fy = pos.y - fly, fz = pos.z - flz;
-  const AxisTerm X[2] = {se_axis_x(m, lx), se_axis_x(m, lx + 1)}, Y[2] = {se_axis_y(m, ly), se_axis_y(m, ly + 1)}, Z[2] = {se_axis_z(m, lz), se_axis_z(m, lz + 1)};
+  const AxisTerm X[2] = {se_axis_x(lx), se_axis_x(lx + 1)}, Y[2] = {se_axis_y(m, ly), se_axis_y(m, ly + 1)}, Z[2] = {se_axis_z(m, lz), se_axis_z(m, lz + 1)};
   float p[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) p[k] = m.vx[se_axis_index(X[k & 1], Y[(k >> 1) & 1], Z[k >> 2])];
@@ -1342,7 +1341,7 @@ __device__ __forceinline__ f3 se_grad(const DevMap& m, const FieldConst fc, f3 p
   // indices 0, 1 are clamped from below only (octree.hpp:658-663): they leave the volume when the point does
   if (!(bx <= hi && by <= hi && bz <= hi)) return se_grad_generic<DENSE>(m, fc, pos, c);
   const float fx = pos.x - flx, fy = pos.y - fly, fz = pos.z - flz;
-  const AxisTerm X[4] = {se_axis_x(m, max(bx - 1, 0)), se_axis_x(m, max(bx, 0)), se_axis_x(m, min(bx + 1, hi)), se_axis_x(m, min(bx + 2, hi))};
+  const AxisTerm X[4] = {se_axis_x(max(bx - 1, 0)), se_axis_x(max(bx, 0)), se_axis_x(min(bx + 1, hi)), se_axis_x(min(bx + 2, hi))};
   const AxisTerm Y[4] = {se_axis_y(m, max(by - 1, 0)), se_axis_y(m, max(by, 0)), se_axis_y(m, min(by + 1, hi)), se_axis_y(m, min(by + 2, hi))};
   const AxisTerm Z[4] = {se_axis_z(m, max(bz - 1, 0)), se_axis_z(m, max(bz, 0)), se_axis_z(m, min(bz + 1, hi)), se_axis_z(m, min(bz + 2, hi))};
   float V[4][4][4];
@@ -1680,18 +1679,18 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 template <bool O32> struct SeDense;
 template <> struct SeDense<true> {     // byte-offset terms, 32 bit
   typedef uint32_t idx_t;
-  static __device__ __forceinline__ idx_t tx(const DevMap& m, uint32_t x) { return (se_blk_term(x >> 3, 0, m.leaf_level) << 12) | ((x & 7u) << 2); }
-  static __device__ __forceinline__ idx_t ty(const DevMap& m, uint32_t y) { return (se_blk_term(y >> 3, 1, m.leaf_level) << 12) | ((y & 7u) << 5); }
-  static __device__ __forceinline__ idx_t tz(const DevMap& m, uint32_t z) { return (se_blk_term(z >> 3, 2, m.leaf_level) << 12) | ((z & 7u) << 8); }
+  static __device__ __forceinline__ idx_t tx(const DevMap&, uint32_t x) { return ((x >> 3) << 12) | ((x & 7u) << 2); }
+  static __device__ __forceinline__ idx_t ty(const DevMap& m, uint32_t y) { return ((y >> 3) << (12 + m.leaf_level)) | ((y & 7u) << 5); }
+  static __device__ __forceinline__ idx_t tz(const DevMap& m, uint32_t z) { return ((z >> 3) << (12 + 2 * m.leaf_level)) | ((z & 7u) << 8); }
   static __device__ __forceinline__ idx_t sum(idx_t a, idx_t b, idx_t c) { return a + b + c; }
   static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return *(const float*)((const char*)m.vx + (size_t)i); }
   static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return *(const float*)((const char*)m.vx + (size_t)i + 2048); }
 };
 template <> struct SeDense<false> {    // (block sum, local sum) in 32 bit each, widened at the load
   struct idx_t { uint32_t blk, loc; };
-  static __device__ __forceinline__ idx_t tx(const DevMap& m, uint32_t x) { return {se_blk_term(x >> 3, 0, m.leaf_level), x & 7u}; }
-  static __device__ __forceinline__ idx_t ty(const DevMap& m, uint32_t y) { return {se_blk_term(y >> 3, 1, m.leaf_level), (y & 7u) << 3}; }
-  static __device__ __forceinline__ idx_t tz(const DevMap& m, uint32_t z) { return {se_blk_term(z >> 3, 2, m.leaf_level), (z & 7u) << 6}; }
+  static __device__ __forceinline__ idx_t tx(const DevMap&, uint32_t x) { return {x >> 3, x & 7u}; }
+  static __device__ __forceinline__ idx_t ty(const DevMap& m, uint32_t y) { return {(y >> 3) << m.leaf_level, (y & 7u) << 3}; }
+  static __device__ __forceinline__ idx_t tz(const DevMap& m, uint32_t z) { return {(z >> 3) << (2 * m.leaf_level), (z & 7u) << 6}; }
   static __device__ __forceinline__ idx_t sum(idx_t a, idx_t b, idx_t c) { return {a.blk + b.blk + c.blk, a.loc + b.loc + c.loc}; }
   static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return m.vx[((size_t)i.blk << 10) | i.loc]; }
   static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return m.vx[(((size_t)i.blk << 10) | i.loc) + 512]; }

@@ -100,6 +100,12 @@ class ShardedPipeline:
     ordered on an exchange stream that only waits for the sweep of frame f, so both hide behind the
     raycast of frame f, which runs on the main stream; the main stream joins the exchange stream
     before it inserts the other ranks' keys.  The host never synchronises inside ``frame``.
+
+    Ordering contract for the depth image: ``frame`` enqueues on the streams chosen at construction -- torch's current stream then, or, if
+    that was the legacy default stream (handle 0, on which the library cannot launch), a private stream joined to it ONCE, at construction.  A caller that
+    produces each frame's depth image on the device must therefore either produce it on ``self.main`` / ``self.xs`` (``with torch.cuda.stream(sp.xs or
+    sp.main)``) or make those streams wait for its producer before calling ``frame`` (``sp.main.wait_stream(producer)``, and ``sp.xs`` likewise); images
+    that are resident before the loop starts (bench.py, the tests) need nothing.
     """
 
     def __init__(self, input_size, volume_resolution, volume_dimension, field_type, rank, world, device,

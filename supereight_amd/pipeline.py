@@ -44,6 +44,7 @@ EXPORTS = {
     "se_hip_destroy": (C.c_int, [C.c_void_p]),
     "se_hip_last_error": (C.c_char_p, []),
     "se_hip_sync": (C.c_int, [C.c_void_p]),
+    "se_hip_memory_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "se_hip_clear_overflow": (C.c_int, [C.c_void_p]),
     "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -448,6 +449,12 @@ class DenseSLAMPipeline:
         v, n = C.c_void_p(), C.c_void_p()
         self._check(self.lib.se_hip_vertex_normal_device(self._h, C.byref(v), C.byref(n)))
         return v.value, n.value
+
+    def memory_info(self) -> dict:
+        """Layout and device memory of the map: dense brick grid or pooled bricks, brick slots, bytes of the bricks / of the whole replica."""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.se_hip_memory_info(self._h, out))
+        return {"layout": "dense brick grid" if out[0] else "pooled bricks", "brick_slots": int(out[1]), "brick_bytes": int(out[2]), "device_bytes": int(out[3])}
 
     def counts(self):
         nb, nn = C.c_int32(), C.c_int32()
