@@ -1670,9 +1670,6 @@ struct RayCounters { unsigned long long n_get, n_interp; unsigned n_batch; };
 #define SE_MARCH_SKIP 4    // SDF march in unobserved space: positions asked of the leaf bitmap per round trip (se_march_skip); 0 = off.  Measured 0 / 4 / 8
                            // (profiles/r04p_march_skip_ab.log): 59.8 / 59.8 / 61.6 us per frame at 512^3, 193.8 / 188.4 / 189.5 at 1024^3, stress 69.7 / 68.6 / 71.3
 #endif
-#ifndef SE_BAND_SOLO
-#define SE_BAND_SOLO 1     // dense SDF march inside the truncation band: one sample per batch, taken from its interpolation cell (se_cast_ray_sdf_lean); 0 = the r05 form (A/B)
-#endif
 #ifndef SE_POOLED_CELL
 #define SE_POOLED_CELL 1   // pooled SDF march: the interpolation cell of sample 0 fetched with the batch when it lies inside the sample's brick; 0 = off (A/B)
 #endif
@@ -1698,7 +1695,7 @@ template <> struct SeDense<false> {    // (block sum, local sum) in 32 bit each,
   static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return m.vx[((size_t)i.blk << 10) | i.loc]; }
   static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return m.vx[(((size_t)i.blk << 10) | i.loc) + 512]; }
 };
-template <bool O32> struct SeCell { float fx, fy, fz; typename SeDense<O32>::idx_t vi[8]; bool inside, nonneg; };   // nonneg: floor(pos) >= 0 on every axis (then corner 0 IS the voxel get() reads)
+template <bool O32> struct SeCell { float fx, fy, fz; typename SeDense<O32>::idx_t vi[8]; bool inside; };
 // the interpolation cell of a point given in voxel units (Octree::interp, octree.hpp:541-563): fractions and the eight
 // corner indices; inside = the whole cell lies in the volume (else the caller takes se_interp_generic)
 template <bool O32>
@@ -1711,7 +1708,6 @@ __device__ __forceinline__ SeCell<O32> se_cell_lean(const DevMap& m, f3 pos) {
   const int lx = max(bx, 0), ly = max(by, 0), lz = max(bz, 0);
   const int top = m.size - 1;
   cell.inside = max(max(lx, ly), lz) < top;
-  cell.nonneg = (bx | by | bz) >= 0;
   const typename A::idx_t X[2] = {A::tx(m, lx), A::tx(m, lx + 1)}, Y[2] = {A::ty(m, ly), A::ty(m, ly + 1)}, Z[2] = {A::tz(m, lz), A::tz(m, lz + 1)};
 #pragma unroll
   for (int k = 0; k < 8; ++k) cell.vi[k] = A::sum(X[k & 1], Y[(k >> 1) & 1], Z[k >> 2]);
@@ -1859,32 +1855,13 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
     // the next z slice of its voxel, profiles/r06e_extrapolate_ab.log.  Likewise a prefetch of the brick lines around the depth image's own estimate of the
     // hit point, issued when the march starts: +-0, profiles/r06d_prefetch_ab.log.  A batch of those rays is two dependent round trips and ~400 instructions
     // of a wave alone on its SIMD whatever the cache state.)
-    // Inside the truncation band (r06) a batch is ONE sample with its interpolation cell: the speculative second sample is all but never consumed there
-    // (the step is the shrinking distance to the surface: never the size of the last one), and the voxel get() reads is corner 0 of the cell
-    // (trunc = floor for a position inside the volume), so the batch is the cell's eight x values + one y value -- ~60 instructions and three loads fewer
-    // on the chain of exactly the rays that end the launch (grazing incidence: ~16 such batches, profiles/r06b_wave_timeline_*).  Where the step does
-    // repeat inside the band (creeping at the minimum step) the second sample needed a round trip of its own for its cell anyway.
-    SeCell<O32> cell0;
-    float cv0[8];
-    bool have0 = false, solo = false;
-    float x0, y0, x1 = 0.f, y1 = 0.f;
-    SeSample<O32> s0, s1;
-    s1.in = false;
-    if (SE_BAND_SOLO && band) {
-      cell0 = se_cell_lean<O32>(m, f3_scale(a.inv_voxel, q0));
-      solo = cell0.inside && cell0.nonneg;
-      if (solo) {
-        have0 = true;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cv0[k] = A::ldx(m, cell0.vi[k]);
-        y0 = A::ldy(m, cell0.vi[0]);
-        x0 = cv0[0];
-        s0.in = true; s0.vi = cell0.vi[0];
-      }
-    }
-    if (!solo) {
+    // (r06, measured and dropped: inside the band a batch of ONE sample taken from its interpolation cell -- the voxel get() reads is the cell's corner 0, and
+    // the speculative second sample is rarely consumed where the step is the shrinking distance to the surface -- ~60 instructions and three loads fewer per
+    // in-band batch: fused launch 36.5 -> 39.0 us at 512^3, 17.3 k -> 16.6 k frames/s, stress stream -3.5 %: where the march creeps at the minimum step the
+    // second sample IS consumed, and a batch of one doubles the loop's fixed cost there; profiles/r06j_band_solo_ab.log)
     const f3 q1 = f3_add(q0, f3_scale(S, dir));
-    s0 = se_sample_lean<O32>(m, a, q0); s1 = se_sample_lean<O32>(m, a, q1);
+    SeSample<O32> s0 = se_sample_lean<O32>(m, a, q0), s1 = se_sample_lean<O32>(m, a, q1);
+    float x0, y0, x1, y1;
     bool probed = false;
     if constexpr (SE_MARCH_PROBE && !O32) {
      if (unobs) {
@@ -1902,18 +1879,19 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
      }
     }
     if (!probed) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
-    if (band) {      // (SE_BAND_SOLO = 0, or a cell on the volume's boundary: the r05 form, corners beside the two samples)
-      if (!SE_BAND_SOLO) cell0 = se_cell_lean<O32>(m, f3_scale(a.inv_voxel, q0));
+    SeCell<O32> cell0;
+    float cv0[8];
+    bool have0 = false;
+    if (band) {
+      cell0 = se_cell_lean<O32>(m, f3_scale(a.inv_voxel, q0));
       have0 = cell0.inside;
       if (have0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) cv0[k] = A::ldx(m, cell0.vi[k]);
       }
     }
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (i == 1 && solo) break;
       if (!(t < tfar)) { done = true; break; }
       if (STATS) ++rc.n_get;
       const bool ok = i ? s1.in : s0.in;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The evidence runs of a round (one gpurun call each; r04: tags r04m, r04r, r04u, r04y -- r05: r05k, r05z):
+# The evidence runs of a round (one gpurun call each; r04: tags r04m, r04r, r04u, r04y -- r05: r05k, r05z -- r06: r06k (final + last + gloo2)):
 #   tools/gpu_evidence.sh final [tag]   full rocprofv3 passes (kernel trace + FETCH / WRITE / SQ / cache / TLB / latency counters, separate runs) of the
 #                                           four BASELINE workloads that fit one GPU, then configs 2..5 + the stress stream through bench.py   (r04m, r04r)
 #   tools/gpu_evidence.sh last [tag]    smoke, every GPU test, the driver's two bench commands, the tracked loop's probe + kernel trace, configs + stress (r04u)
@@ -7,7 +7,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 MODE=${1:-close}
-T=${2:-r05}
+T=${2:-r06}
 configs_and_stress() {
   SE_CFG_SKIP_MU01=1 bash tools/gpu_configs.sh 2>&1 | tee gpurun_out/${T}_configs.log | cut -c1-320
   for t in sdf512 sdf512_icl sdf1024 sdf2048 ofusion512; do cp gpurun_out/cfg_$t.json gpurun_out/${T}_cfg_$t.json; done
@@ -36,5 +36,13 @@ case $MODE in
     keep_profile $T
     grep -E "k_raycast|k_integrate|k_alloc_scan" gpurun_out/${T}_rocprofv3_summary.md | head -12 | cut -c1-200
     bash tools/gpu_run.sh $T smoke tests bench driver ;;
-  *) echo "usage: $0 final|last|close [tag]" ;;
+  gloo2)
+    # code-path dry run of the N > 1 bench on ONE GPU: two ranks over gloo, both schedules; the line is not a performance figure
+    for mode in two_queue one_queue; do
+      extra=""; [ $mode = one_queue ] && extra="--sharded-streaming"
+      SE_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline $extra > gpurun_out/${T}_bench_gloo2_dryrun_$mode.json 2> gpurun_out/${T}_gloo2_$mode.err
+      python -c "
+import json; d=json.load(open('gpurun_out/${T}_bench_gloo2_dryrun_$mode.json')); print('gloo2 $mode', round(d['value']), d['n_gpus'], d['config'].get('blocks_allocated'), d['config']['schedule'][:60])" || tail -5 gpurun_out/${T}_gloo2_$mode.err
+    done ;;
+  *) echo "usage: $0 final|last|close|gloo2 [tag]" ;;
 esac
