@@ -1535,6 +1535,15 @@ __device__ __forceinline__ RaySpan se_first_leaf(const DevMap& m, const RayArgs&
 // (se_beam_start) that no allocated block lies within centimetres of the ray before t_start, so the first leaf and the plane through which the ray
 // enters it are the same -- and t_min at the leaf is that plane's time, `plane * t_coef - t_bias` of the cell left last, whatever cells came before.
 // Should the search end without ever having advanced (t_min still t_start: it would be returning t_start as an entry time) the ray is handed back.
+// (r06, measured and dropped: the search as a walk over the leaf grid alone -- one geometric descent to the leaf-size cell at t_min by the iterator's own
+// t_center comparisons, then advance_ray at the leaf scale, eight cells computed ahead per round trip and their leaf-bitmap words fetched together (the cell
+// sequence does not depend on what is loaded), `t_parent <= t_lim` standing in for the iterator's descent rule.  On the CPU model (fl::flat in
+// tests/cpp/first_leaf_equiv.cpp) that is 6.9 steps of ~30 instructions instead of 10.4 trips of 70-110 per ray at 512^3, 15.6 against 13.9 at 1024^3.  On
+// the device (profiles/r06m_flat_walk_ab.log): raycast beside the scan 35.1 -> 35.0 us at 512^3, 69.2 -> 65.3 us at 1024^3, 163 -> 192 us at 2048^3, the
+// stress streams 6-12 % slower -- every wave pays the descent, a full batch and an L2 round trip where the hierarchical search reads LDS, and the last waves
+// of a launch are bound by their march, not by their search.  It is also not exact as it stands: where two plane crossings fall within rounding of each
+// other the iterator's placement by t_center and the walk's order by t_corner differ, about one ray in 10^6-10^7 enters its block through the other plane
+// (8 ulp in t_min); that would need a near-tie test per cell on top.)
 template <bool SHALLOW, typename Hook = SeNoHook>
 __device__ __forceinline__ RaySpan se_first_leaf_lite(const DevMap& m, const RayArgs& a, f3 origin, f3 direction, const uint32_t* s_occ,
                                                       bool& redo, Hook before_loop = Hook(), bool live = true, float t_start = 0.f) {

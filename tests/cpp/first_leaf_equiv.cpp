@@ -29,7 +29,7 @@
 
 namespace fl {
 
-struct Result { float t_min; int found; int flagged; int irregular; int trips; };
+struct Result { float t_min; int found; int flagged; int irregular; int trips; float t_lim; };
 static thread_local int* g_adv_hist = nullptr;   // (experiments: advances per scale, descents at [32 + scale])
 
 // the node whose children are the cells of `scale`, found from pos alone (what `code >> 3 * levels` is on the device)
@@ -43,7 +43,7 @@ template <typename VT> static Node<VT>* node_at(const Octree<VT>& m, V3f pos, in
 }
 
 template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f direction, float nearP, float farP, float t_start = 0.f) {
-  Result r = {0.f, 0, 0, 0, 0};
+  Result r = {0.f, 0, 0, 0, 0, 0.f};
   V3f pos = {1.f, 1.f, 1.f};
   int scale = CAST_STACK_DEPTH - 1;
   float scale_exp2 = 0.5f;
@@ -111,6 +111,87 @@ template <typename VT> static Result lite(const Octree<VT>& m, V3f origin, V3f d
     }
   }
   if (jumped && t_min == t_start && !r.flagged) r.flagged = 1;   // never advanced: would return t_start as an entry time -> handed back
+  r.t_min = t_min;
+  return r;
+}
+
+// r06 experiment: the first leaf by a FLAT walk over leaf-size cells (no tree, no descents, no pops): the iterator's own plane times t = pos * t_coef - t_bias
+// decide every step, so the time at which the walk enters the first allocated leaf is the iterator's t_min bit for bit -- the plane through which a ray
+// enters a cell is the same plane whatever cells came before.  What the tree adds to the reference's answer is only its far-plane rule: a node is descended
+// into while t_min <= t_max, leaves of a node already entered are returned whatever their distance -- i.e. a leaf counts iff its PARENT cell (level
+// leaf - 1) was entered at t <= t_lim.  Flags (handed back to the full iterator): a cell entered after its own exit time (the rounding artefact `lite` flags
+// at descents), and, if `flag_ties`, a step that crosses two planes at the same float time.
+// Outcome (se_kernels.h, in front of se_first_leaf_lite; profiles/r06m_flat_walk_ab.log): not adopted.  On the device it was no faster (512^3 +-0, 2048^3 and the
+// stress streams slower), and "bit for bit" above holds only away from near-ties: the iterator places a ray inside a cell it descends into by t_center
+// (half * t_coef + t_corner), the walk orders the same planes by t_corner of the leaf cells, and where two crossings fall within a few ulp the two disagree about
+// which plane the ray entered its block through -- stress stream, 640x480, 512^3, frame 11, pixel (224, 222): t_min 0.28818703 instead of 0.28818679.  About one
+// ray in 10^6-10^7; the streams below did not contain one.  Kept as the record of the experiment; nothing on the product path uses it.
+template <typename VT> static Result flat(const Octree<VT>& m, V3f origin, V3f direction, float nearP, float farP, float t_start, bool flag_ties) {
+  Result r = {0.f, 0, 0, 0, 0, 0.f};
+  const int min_scale = CAST_STACK_DEPTH - (int)std::log2((double)(m.size_ / BLOCK_SIDE));
+  const float epsilon = exp2f(-(float)std::log2((double)m.size_));
+  V3f d;
+  d.x = fabsf(direction.x) < epsilon ? copysignf(epsilon, direction.x) : direction.x;
+  d.y = fabsf(direction.y) < epsilon ? copysignf(epsilon, direction.y) : direction.y;
+  d.z = fabsf(direction.z) < epsilon ? copysignf(epsilon, direction.z) : direction.z;
+  const V3f so = origin / m.dim_ + V3f{1.f, 1.f, 1.f};
+  const V3f tc = -1.f * V3f{1.f / fabsf(d.x), 1.f / fabsf(d.y), 1.f / fabsf(d.z)};
+  V3f tb = cwise(tc, so);
+  int om = 0;
+  if (d.x > 0.f) om ^= 1, tb.x = 3.f * tc.x - tb.x;
+  if (d.y > 0.f) om ^= 2, tb.y = 3.f * tc.y - tb.y;
+  if (d.z > 0.f) om ^= 4, tb.z = 3.f * tc.z - tb.z;
+  float t_min = fmaxf(fmaxf(2.f * tc.x - tb.x, 2.f * tc.y - tb.y), 2.f * tc.z - tb.z);
+  const float h0 = fminf(fminf(tc.x - tb.x, tc.y - tb.y), tc.z - tb.z);
+  t_min = fmaxf(t_min, nearP / m.dim_);
+  const float t_lim = fminf(h0, farP / m.dim_);
+  r.t_lim = t_lim;
+  if (!(t_min < h0)) { r.irregular = 1; r.t_min = t_min; return r; }
+  const bool jumped = t_start > t_min;
+  if (jumped) t_min = t_start;
+  if (!(t_min < h0)) { r.t_min = t_min; return r; }   // the beam is clear beyond this ray's own exit from the cube: nothing to find (t_min >= t_lim)
+  // the leaf-size cell the ray is in at t_min: the iterator's own child choices, level by level (no tree needed for them)
+  V3f pos = {1.f, 1.f, 1.f};
+  if (1.5f * tc.x - tb.x > t_min) pos.x = 1.5f;
+  if (1.5f * tc.y - tb.y > t_min) pos.y = 1.5f;
+  if (1.5f * tc.z - tb.z > t_min) pos.z = 1.5f;
+  float e = 0.5f;
+  for (int s = CAST_STACK_DEPTH - 1; s > min_scale; --s) {
+    const V3f t_corner = cwise(pos, tc) - tb;
+    const float tcm = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
+    if (tcm < t_min) { r.flagged = 1; r.t_min = t_min; return r; }
+    const float half = e * 0.5f;
+    const V3f t_center = half * tc + t_corner;
+    if (t_center.x > t_min) pos.x += half;
+    if (t_center.y > t_min) pos.y += half;
+    if (t_center.z > t_min) pos.z += half;
+    e = half;
+  }
+  float t_parent = t_min;   // when the current leaf-parent cell was entered
+  for (;;) {
+    ++r.trips;
+    Node<VT>* lp = node_at(m, pos, min_scale, om);
+    const int idx = ((f2i(pos.x) >> min_scale) & 1) | (((f2i(pos.y) >> min_scale) & 1) << 1) | (((f2i(pos.z) >> min_scale) & 1) << 2);
+    if (lp && lp->child(idx ^ om) && t_parent <= t_lim) { r.found = 1; break; }
+    const V3f t_corner = cwise(pos, tc) - tb;
+    const float tcm = fminf(fminf(t_corner.x, t_corner.y), t_corner.z);
+    if (tcm < t_min) { r.flagged = 1; break; }
+    const V3f old = pos;
+    int nax = 0;
+    if (t_corner.x <= tcm) pos.x -= e, ++nax;
+    if (t_corner.y <= tcm) pos.y -= e, ++nax;
+    if (t_corner.z <= tcm) pos.z -= e, ++nax;
+    t_min = tcm;
+    if (flag_ties && nax > 1) { r.flagged = 1; break; }
+    const unsigned diff = (unsigned)(f2i(old.x) ^ f2i(pos.x)) | (unsigned)(f2i(old.y) ^ f2i(pos.y)) | (unsigned)(f2i(old.z) ^ f2i(pos.z));
+    if (diff >= (1u << CAST_STACK_DEPTH)) break;                 // left the cube: nothing found
+    if (diff >= (1u << (min_scale + 1))) {                       // a new leaf-parent cell
+      t_parent = t_min;
+      if (t_min > t_lim) break;                                  // the iterator descends into no further node
+    }
+    if (r.trips > 100000) { r.flagged = 2; break; }
+  }
+  if (jumped && t_min == t_start && !r.flagged) r.flagged = 1;
   r.t_min = t_min;
   return r;
 }
@@ -189,6 +270,8 @@ template <typename VT> static float beam_start(const Octree<VT>& m, const std::v
 }
 
 template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm, const float* k, int64_t* out, int32_t* first_bad, int beam) {
+  const bool use_flat = (beam & 0x100) != 0, flat_ties = (beam & 0x200) != 0;   // (r06 experiment: the flat walk instead of `lite`)
+  beam &= 0xFF;
   const M4 view = mul(from_colmajor(pose_cm), inverse_camera_matrix(k));
   const Octree<VT>& oct = p->oct;
   const int C = std::min(oct.max_level_ - 3, 5);
@@ -219,14 +302,18 @@ template <typename VT> static void compare(Pipeline<VT>* p, const float* pose_cm
       const bool ref_found = ray.next() != nullptr;
       const float ref_t = ray.t_min_;
       trips_ref += g_ray_iter;
-      const Result r = lite(oct, transl, dir, nearPlane, farPlane, beam ? tile_start[(size_t)(y / 8) * tiles_x + x / 8] : 0.f);
+      const float ts = beam ? tile_start[(size_t)(y / 8) * tiles_x + x / 8] : 0.f;
+      const Result r = use_flat ? flat(oct, transl, dir, nearPlane, farPlane, ts, flat_ties) : lite(oct, transl, dir, nearPlane, farPlane, ts);
       ++rays;
       trips_lite += r.trips;
       if (r.irregular) { ++irregular; continue; }
       if (r.flagged == 2) { ++model_bug; continue; }
       if (r.flagged) { ++flagged; continue; }
       found += r.found;
-      if (f2i(r.t_min) != f2i(ref_t) || (r.found != 0) != ref_found) {
+      // (the flat walk stops at the far plane: a ray that finds nothing only has to agree on "t_min is not in front of t_max", which is all raycastKernel
+      // looks at then -- rendering.cpp:60-62: raycast(...) is entered with tnear = t_min, tfar = tmax and returns at once)
+      const bool both_none = use_flat && !r.found && !ref_found && r.t_min >= r.t_lim && ref_t >= r.t_lim;
+      if (!both_none && (f2i(r.t_min) != f2i(ref_t) || (r.found != 0) != ref_found)) {
         ++mismatch;
 #pragma omp critical
         { bad_x = x; bad_y = y; }
@@ -284,5 +371,7 @@ extern "C" void fl_debug(void* pipe, const float* pose_cm, const float* k, int x
   RayIterator<SDFv> ray(oct, transl, dir, nearPlane, farPlane);
   const bool ref_found = ray.next() != nullptr;
   const fl::Result a = fl::lite(oct, transl, dir, nearPlane, farPlane, 0.f), b = fl::lite(oct, transl, dir, nearPlane, farPlane, ts);
+  { const fl::Result f = fl::flat(oct, transl, dir, nearPlane, farPlane, ts, false);
+    out[10] = f.t_min * oct.dim_; out[11] = f.found; out[12] = f.flagged; out[13] = f.trips; out[14] = ray.t_min_; out[15] = f.t_min; }
   out[0] = ts * oct.dim_; out[1] = ray.t_min_ * oct.dim_; out[2] = ref_found; out[3] = a.t_min * oct.dim_; out[4] = a.found; out[5] = b.t_min * oct.dim_; out[6] = b.found; out[7] = b.flagged; out[8] = a.trips; out[9] = b.trips;
 }
