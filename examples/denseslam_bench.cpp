@@ -40,6 +40,7 @@ struct Stream {
   std::vector<Eigen::Matrix4f> pose;
   std::vector<float> depth;               // F x W*H, host
   std::vector<unsigned short> depth_mm;   // the same frames as the sensor delivers them
+  unsigned short* depth_mm_pinned = nullptr;   // ... and in page-locked memory (DenseSLAMSystem::allocateInput): what a reader that decodes into pinned buffers hands over
   float* dev = nullptr;                   // F x W*H, HBM
   bool load(const char* path) {
     FILE* f = std::fopen(path, "rb");
@@ -57,12 +58,15 @@ struct Stream {
     }
     std::fclose(f);
     for (size_t i = 0; i < depth.size(); ++i) depth_mm[i] = (unsigned short)(depth[i] * 1000.f + 0.5f);
+    depth_mm_pinned = (unsigned short*)DenseSLAMSystem::allocateInput(depth_mm.size() * sizeof(unsigned short));
+    if (!depth_mm_pinned) return false;
+    std::copy(depth_mm.begin(), depth_mm.end(), depth_mm_pinned);
     if (hipMalloc((void**)&dev, depth.size() * sizeof(float)) != hipSuccess) return false;
     return hipMemcpy(dev, depth.data(), depth.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
   }
 };
 
-Configuration make_config(int res, float dim, float mu, const float k[4], bool streaming) {
+Configuration make_config(int res, float dim, float mu, const float k[4], bool streaming, bool pinned) {
   Configuration c;
   c.compute_size_ratio = 1; c.tracking_rate = 1; c.integration_rate = 1; c.rendering_rate = 4;
   c.volume_resolution = Eigen::Vector3i(res, res, res); c.volume_size = Eigen::Vector3f(dim, dim, dim);
@@ -71,6 +75,7 @@ Configuration make_config(int res, float dim, float mu, const float k[4], bool s
   c.mu = mu; c.fps = 0; c.blocking_read = false; c.icp_threshold = 1e-5f; c.no_gui = true;
   c.render_volume_fullsize = false; c.bilateralFilter = false; c.colouredVoxels = false; c.multiResolution = false; c.bayesian = false;
   c.hip_streaming = streaming;
+  c.hip_pinned_input = pinned;
   return c;
 }
 
@@ -78,10 +83,11 @@ struct Pass { double fps = 0, integration_ms = 0, raycasting_ms = 0, preprocessi
 
 enum Mode { CLOSED, STREAMING, UPLOAD, STREAMING_UPLOAD, TRACKED };
 
-Pass run(const Stream& s, int res, float dim, float mu, int warm, int frames, Mode mode, FILE* log) {
+Pass run(const Stream& s, int res, float dim, float mu, int warm, int frames, Mode mode, FILE* log, bool pinned = false) {
   std::vector<int> pyramid = {10, 5, 4};
   const bool stream_mode = mode == STREAMING || mode == STREAMING_UPLOAD;
-  const Configuration config = make_config(res, dim, mu, s.k, mode != CLOSED && mode != UPLOAD);
+  const Configuration config = make_config(res, dim, mu, s.k, mode != CLOSED && mode != UPLOAD, pinned);
+  const unsigned short* host_mm = pinned ? s.depth_mm_pinned : s.depth_mm.data();
   DenseSLAMSystem pipeline(Eigen::Vector2i(s.W, s.H), config.volume_resolution, config.volume_size, Eigen::Vector3f(0.f, 0.f, 0.f), pyramid, config);
   const Eigen::Vector4f camera(s.k[0], s.k[1], s.k[2], s.k[3]);
   const size_t n = (size_t)s.W * s.H;
@@ -92,7 +98,7 @@ Pass run(const Stream& s, int res, float dim, float mu, int warm, int frames, Mo
   for (int frame = 0; frame < warm + frames; ++frame) {
     if (frame == warm) { synchroniseDevices(); t_begin = Clock::now(); timings[0] = t_begin; }
     timings[1] = Clock::now();
-    if (mode == UPLOAD || mode == STREAMING_UPLOAD || mode == TRACKED) pipeline.preprocessing(&s.depth_mm[n * frame], Eigen::Vector2i(s.W, s.H), false);
+    if (mode == UPLOAD || mode == STREAMING_UPLOAD || mode == TRACKED) pipeline.preprocessing(host_mm + n * frame, Eigen::Vector2i(s.W, s.H), false);
     else pipeline.preprocessingDevice(s.dev + n * frame);
     timings[2] = Clock::now();
     bool tracked = true;
@@ -147,17 +153,24 @@ int main(int argc, char** argv) {
   const Pass upload = run(s, res, dim, mu, warm, frames, UPLOAD, nullptr);
   const Pass stream_up = run(s, res, dim, mu, warm, frames, STREAMING_UPLOAD, nullptr);
   const Pass tracked = run(s, res, dim, mu, warm, frames, TRACKED, nullptr);
+  // the three host-input passes again with the frames in page-locked memory and Configuration::hip_pinned_input: no copy into the handle's own ring
+  const Pass upload_p = run(s, res, dim, mu, warm, frames, UPLOAD, nullptr, true);
+  const Pass stream_up_p = run(s, res, dim, mu, warm, frames, STREAMING_UPLOAD, nullptr, true);
+  const Pass tracked_p = run(s, res, dim, mu, warm, frames, TRACKED, nullptr, true);
   if (log) std::fclose(log);
   std::printf("{\"surface\": \"DenseSLAMSystem (include/se/DenseSLAMSystem.h) over libse_hip.so\", \"frames\": %d, \"warmup\": %d, \"blocks\": %d, "
               "\"closed_loop_fps\": %.1f, \"closed_loop_stage_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
               "\"streaming_fps\": %.1f, \"streaming_enqueue_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
               "\"closed_loop_fps_with_upload\": %.1f, \"upload_stage_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
               "\"streaming_fps_with_upload\": %.1f, \"streaming_upload_enqueue_ms\": {\"preprocessing\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
-              "\"tracked_fps_with_upload\": %.1f, \"tracked_stage_ms\": {\"preprocessing\": %.4f, \"tracking\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}}\n",
+              "\"tracked_fps_with_upload\": %.1f, \"tracked_stage_ms\": {\"preprocessing\": %.4f, \"tracking\": %.4f, \"integration\": %.4f, \"raycasting\": %.4f}, "
+              "\"pinned_input\": {\"closed_loop_fps_with_upload\": %.1f, \"preprocessing_ms\": %.4f, \"streaming_fps_with_upload\": %.1f, \"tracked_fps_with_upload\": %.1f}}\n",
               frames, warm, closed.blocks, closed.fps, closed.preprocessing_ms, closed.integration_ms, closed.raycasting_ms, streaming.fps,
               streaming.preprocessing_ms, streaming.integration_ms, streaming.raycasting_ms, upload.fps, upload.preprocessing_ms, upload.integration_ms,
               upload.raycasting_ms, stream_up.fps, stream_up.preprocessing_ms, stream_up.integration_ms, stream_up.raycasting_ms,
-              tracked.fps, tracked.preprocessing_ms, tracked.tracking_ms, tracked.integration_ms, tracked.raycasting_ms);
+              tracked.fps, tracked.preprocessing_ms, tracked.tracking_ms, tracked.integration_ms, tracked.raycasting_ms,
+              upload_p.fps, upload_p.preprocessing_ms, stream_up_p.fps, tracked_p.fps);
   hipFree(s.dev);
+  DenseSLAMSystem::freeInput(s.depth_mm_pinned);
   return 0;
 }

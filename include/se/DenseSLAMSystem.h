@@ -77,6 +77,7 @@ class DenseSLAMSystem {
     /* The class never hands out device pointers: every way an application can look at vertex_ / normal_ (tracking, render*, getVertexNormal)
      * is an API call that launches a held-back raycast first, so the one-queue streaming schedule is safe by construction here. */
     if (config.hip_streaming) se_hip_set_streaming(h_, 1);
+    if (config.hip_pinned_input) se_hip_set_pinned_input(h_, 1);
     live().push_back(h_);
   }
   ~DenseSLAMSystem() {
@@ -99,6 +100,9 @@ class DenseSLAMSystem {
   }
   /* the reference's float_depth_ handed over directly (metres) */
   bool preprocessing(const float* depthMetres) { return ok(se_hip_upload_depth(h_, depthMetres)); }
+  /* page-locked host memory for a frame reader's input buffer (Configuration::hip_pinned_input: such images are not copied by preprocessing()) */
+  static void* allocateInput(size_t bytes) { return se_hip_host_alloc(bytes); }
+  static void freeInput(void* host) { se_hip_host_free(host); }
   /* ... or left where a device-side producer put it (HBM, metres, valid until the next call): no copy at all */
   bool preprocessingDevice(const float* deviceDepthMetres) { return ok(se_hip_set_depth_device(h_, deviceDepthMetres)); }
 

@@ -47,6 +47,9 @@ struct Configuration {
   long long hip_max_blocks = 0;        /* > 0: pooled bricks with this capacity instead of the dense brick grid */
   bool hip_streaming = true;           /* raycasting() may be launched together with the next integration()'s allocation scan (se_hip_set_streaming);
                                           nothing an application can observe through DenseSLAMSystem changes */
+  bool hip_pinned_input = false;       /* preprocessing() reads an input image that lies in page-locked memory (DenseSLAMSystem::allocateInput) where it is,
+                                          instead of copying it first: the buffer must then stay unmodified until the frame has been integrated
+                                          (se_hip_set_pinned_input) */
 };
 
 #endif /* SE_HIP_CONFIG_H */

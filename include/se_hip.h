@@ -141,6 +141,16 @@ int se_hip_upload_depth(se_hip_pipeline* p, const float* host_depth_m);
 /* mm2metersKernel (se_denseslam/src/preprocessing.cpp:161-188) applied where the image is first read on the device:
  * uint16 millimetres of size (in_w, in_h), an integer multiple of the computation size ("Invalid ratio." = SE_HIP_E_INVALID). */
 int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_depth_mm, int32_t in_w, int32_t in_h);
+/* Caller-pinned input (opt-in, r06): with se_hip_set_pinned_input(p, 1) an image handed to the two calls above that lies in page-locked host memory
+ * (se_hip_host_alloc below, hipHostMalloc, hipHostRegister) is NOT copied: the frame's first kernel reads it over PCIe where the caller keeps it -- a
+ * reader that decodes its frames straight into such a buffer (the reference's loop reads a frame per iteration, se_apps/src/benchmark.cpp:115-133) saves
+ * the 16 us copy of a 640x480 image per frame.  The price is the reference's synchronous contract: the buffer must stay unmodified until the frame's
+ * integration has run on the device -- i.e. until a call that waits for it has returned (se_hip_sync, an image download, se_hip_track of the next
+ * frame) or, for a streaming caller, until three further uploads have been accepted (the handle's own ring discipline).  Pageable images are copied as
+ * before, whatever the flag says.  se_hip_host_alloc / se_hip_host_free: page-locked host memory without a HIP dependency in the caller (NULL on failure). */
+int se_hip_set_pinned_input(se_hip_pipeline* p, int32_t on);
+void* se_hip_host_alloc(size_t bytes);
+void se_hip_host_free(void* host);
 /* Zero-copy: integrate from a depth image already resident in HBM (width*height floats).  The buffer is read by the
  * allocation scan and by the integration sweep of the frame: it must stay untouched until that sweep has finished
  * (se_hip_sync, or work ordered behind se_hip_integrate on the handle's stream).  It must also be COMPLETE when the handle's streams get to

@@ -120,6 +120,7 @@ struct se_hip_pipeline {
   // Two such launches in a row without a fused one in between -> this caller looks at every frame: raycasts are launched eagerly from then on
   // (se_hip_set_streaming(p, 1) arms deferral again).
   int flush_streak = 0;
+  bool pinned_input = false;   // se_hip_set_pinned_input: page-locked caller images are read in place
   bool ptrs_exposed = false;   // sticky: se_hip_vertex_normal_device handed out vertex_ / normal_ of a handle without an image ring
   float pend_pose[16] = {0}, pend_k[4] = {0}, pend_mu = 0.f;
   uint32_t pend_frame = 0;
@@ -784,8 +785,15 @@ static int stage_input(se_hip_pipeline* p, const void* host, size_t bytes, int k
     HIP_TRY(hipStreamSynchronize(p->stream));
   }
   p->in_state[i] = 0; p->in_event[i] = false;
-  std::memcpy(p->in_host[i], host, bytes);   // (r06, measured: non-temporal stores here took 21 us instead of 16 us for the 614 KB image and moved nothing on the device side)
-  p->in_pending = DepthSrc{p->in_host[i], p->depth_ring[i], kind, in_w, ratio};
+  const void* src = p->in_host[i];
+  if (p->pinned_input) {
+    // caller-pinned image (se_hip_set_pinned_input): read where it lies; the slot only lends its device image and its place in the ring
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) src = at.devicePointer;
+    else (void)hipGetLastError();   // (pageable memory: an error code, not an error)
+  }
+  if (src == p->in_host[i]) std::memcpy(p->in_host[i], host, bytes);   // (r06, measured: non-temporal stores here took 21 us instead of 16 us for the 614 KB image and moved nothing on the device side)
+  p->in_pending = DepthSrc{src, p->depth_ring[i], kind, in_w, ratio};
   p->depth = p->depth_ring[i];
   p->cur_in = i;
   return SE_HIP_OK;
@@ -809,6 +817,18 @@ int se_hip_upload_depth_mm(se_hip_pipeline* p, const uint16_t* host_mm, int32_t 
   if (in_w < W || in_h < H || in_w % W != 0 || in_h % H != 0 || in_w / W != in_h / H) return fail(SE_HIP_E_INVALID, "Invalid ratio.");
   return stage_input(p, host_mm, (size_t)in_w * in_h * sizeof(unsigned short), 1, in_w, in_w / W);   // mm2metersKernel happens where the image is first read
 }
+
+int se_hip_set_pinned_input(se_hip_pipeline* p, int32_t on) {
+  if (!p) return fail(SE_HIP_E_INVALID, "null handle");   // (a flag only: does not launch a deferred raycast)
+  p->pinned_input = on != 0;
+  return SE_HIP_OK;
+}
+void* se_hip_host_alloc(size_t bytes) {
+  void* h = nullptr;
+  if (bytes == 0 || hipHostMalloc(&h, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return h;
+}
+void se_hip_host_free(void* host) { if (host) (void)hipHostFree(host); }
 
 int se_hip_set_depth_device(se_hip_pipeline* p, const float* device_depth_m) {
   if (!p) return fail(SE_HIP_E_INVALID, "null handle");

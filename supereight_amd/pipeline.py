@@ -45,6 +45,9 @@ EXPORTS = {
     "se_hip_last_error": (C.c_char_p, []),
     "se_hip_sync": (C.c_int, [C.c_void_p]),
     "se_hip_memory_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "se_hip_set_pinned_input": (C.c_int, [C.c_void_p, C.c_int32]),
+    "se_hip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "se_hip_host_free": (None, [C.c_void_p]),
     "se_hip_clear_overflow": (C.c_int, [C.c_void_p]),
     "se_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "se_hip_set_scan_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -171,6 +174,7 @@ class DenseSLAMPipeline:
         self.pose_ = np.eye(4, dtype=np.float32) if init_pose is None else init_pose
         self._keepalive = None
         self._ring_keepalive = None
+        self._pinned = []
         if streaming:
             self.set_streaming(True)
 
@@ -230,6 +234,9 @@ class DenseSLAMPipeline:
         if getattr(self, "_h", None):
             self.lib.se_hip_destroy(self._h)
             self._h = None
+            for ptr in getattr(self, "_pinned", []):
+                self.lib.se_hip_host_free(ptr)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -449,6 +456,20 @@ class DenseSLAMPipeline:
         v, n = C.c_void_p(), C.c_void_p()
         self._check(self.lib.se_hip_vertex_normal_device(self._h, C.byref(v), C.byref(n)))
         return v.value, n.value
+
+    def set_pinned_input(self, on: bool = True):
+        """Opt in to zero-copy host input: page-locked images handed to set_depth / set_depth_mm (pinned_image below) are read in place."""
+        self._check(self.lib.se_hip_set_pinned_input(self._h, 1 if on else 0))
+
+    def pinned_image(self, dtype=np.float32, shape=None):
+        """A page-locked numpy image of the computation size (se_hip_host_alloc); freed with the pipeline."""
+        shape = shape or (self.H, self.W)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.lib.se_hip_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError("se_hip_host_alloc failed")
+        self._pinned.append(ptr)
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).view(dtype).reshape(shape)
 
     def memory_info(self) -> dict:
         """Layout and device memory of the map: dense brick grid or pooled bricks, brick slots, bytes of the bricks / of the whole replica."""

@@ -223,3 +223,65 @@ def test_raycast_from_unusual_viewpoints(field, W, H, N, dim, mu, frames):
         total_hits += r["hits_gpu"]
     assert total_hits > 5000      # the sweep looked at surfaces, not only at nothing
     cpu.close(); gpu.close()
+
+
+@pytest.mark.parametrize("streaming", [False, True], ids=["eager", "one-queue"])
+def test_pinned_host_input_is_read_in_place(streaming):
+    """se_hip_set_pinned_input: images in page-locked memory (se_hip_host_alloc) are not copied into the handle's ring -- the frame's first kernel reads them
+    over PCIe where the caller keeps them.  Same frames as uint16 millimetres three ways -- device-resident metres, pageable host images (copied), pinned
+    host images (in place, a ring of four caller buffers: the contract is 'unmodified until three further uploads') -- must give the same map and the same
+    last raycast, bit for bit; a float image goes the same way; a pageable image on a pinned-input handle is still copied (the caller may overwrite it at once)."""
+    import torch
+    from supereight_amd.pipeline import DenseSLAMPipeline
+    from supereight_amd.synthetic import SyntheticStream
+    W, H, N, dim, mu, frames = 320, 240, 256, 2.4, 0.1, 14
+    s = SyntheticStream(W, H, dim)
+    mm = [np.minimum(np.round(s.depth(f) * 1000.0), 65535).astype(np.uint16) for f in range(frames)]
+    metres = [m.astype(np.float32) / np.float32(1000.0) for m in mm]        # mm2metersKernel (preprocessing.cpp:161-188)
+    dev = torch.from_numpy(np.stack(metres)).cuda()
+    k = np.ascontiguousarray(s.k, np.float32)
+
+    def run(kind):
+        p = DenseSLAMPipeline((W, H), N, dim, streaming=streaming)
+        ring = []
+        if kind.startswith("pinned"):
+            p.set_pinned_input(True)
+            ring = [p.pinned_image(np.uint16 if kind == "pinned-mm" else np.float32) for _ in range(4)]
+        scratch = np.empty((H, W), np.uint16)
+        for f in range(frames):
+            if kind == "device":
+                p.set_depth_device(dev[f].data_ptr())
+            elif kind == "pageable":
+                scratch[:] = mm[f]
+                p.set_depth_mm(scratch)
+                scratch[:] = 0                                               # copied: the caller's buffer is free at once
+            elif kind == "pageable-on-pinned-handle":
+                p.set_pinned_input(True)
+                scratch[:] = mm[f]
+                p.set_depth_mm(scratch)
+                scratch[:] = 0
+            elif kind == "pinned-mm":
+                ring[f % 4][:] = mm[f]
+                p.set_depth_mm(ring[f % 4])
+            else:
+                ring[f % 4][:] = metres[f]
+                p.set_depth(ring[f % 4])
+            p.setPose(s.pose(f))
+            p.integration(k, 1, mu, f)
+            p.raycasting_deferred(k, mu, f)
+        v, n = p.vertex_normal()
+        out = (p.blocks(), v, n, p.launch_counts())
+        p.close()
+        return out
+
+    ref = run("device")
+    assert len(ref[0][0]) > 500 and (ref[2][..., 0] != -2).sum() > 1000
+    if streaming:
+        assert ref[3]["fused"] == frames - 4
+    for kind in ("pageable", "pageable-on-pinned-handle", "pinned-mm", "pinned-float"):
+        got = run(kind)
+        for a, b in zip(ref[0], got[0]):
+            assert a.shape == b.shape and (a.view(np.uint8) == b.view(np.uint8)).all(), kind
+        assert (ref[1].view(np.uint32) == got[1].view(np.uint32)).all() and (ref[2].view(np.uint32) == got[2].view(np.uint32)).all(), kind
+        if streaming:
+            assert got[3]["fused"] == frames - 4, kind
