@@ -540,6 +540,9 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
   float T[12];
   int stop_cur = first ? 0 : si->stop[a.level];
   // this lane's first pixels: their inputs do not depend on the pose, so their loads fly under the prologue
+  // (r06, measured and dropped: requesting the previous iteration's partial rows and its pose here as well, before the stop flags are known, so that the
+  // prologue's loads are one round trip instead of two -- tracked loop 4 115 -> 4 072 frames/s, same poses: the flags arrive with the kernel arguments'
+  // first use and the 32 extra loads per lane delay the pixel loads behind them; tools/track_ab.py)
   const int W = a.inW, H = a.inH;
   const int rows = (H - b + 7) / 8;
   const long npx = (long)rows * W;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
 #pragma unroll
     for (int j = 0; j < SE_TRACK_BATCH; ++j) {
       const long i = lo + t + (long)j * SE_TRACK_LANES;
-      const long ii = i < hi ? i : lo;
+      const long ii = i < hi ? i : (lo < npx ? lo : 0);   // (a lane without a pixel reads some pixel of the strip)
       const int y = b + 8 * (int)(ii / W), x = (int)(ii % W);
       inN0[j] = ld3(inNormal, x + y * a.inW);
       inV0[j] = ld3(inVertex, x + y * a.inW);
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(SE_TRACK_LANES) void k_icp_iter(const IcpState* __r
     for (int j = 0; j < SE_TRACK_BATCH; ++j) {
       const long i = base + (long)j * SE_TRACK_LANES;
       const bool live = i < hi;
-      const long ii = live ? i : lo;
+      const long ii = live ? i : (lo < npx ? lo : 0);
       const int y = b + 8 * (int)(ii / W), x = (int)(ii % W);
       if (base == lo + t) { inN[j] = inN0[j]; inV[j] = inV0[j]; }     // (fetched before the prologue)
       else { inN[j] = ld3(inNormal, x + y * a.inW); inV[j] = ld3(inVertex, x + y * a.inW); }
