@@ -1815,6 +1815,7 @@ int se_hip_memory_info(se_hip_pipeline* p, int64_t out[4]) {
   const size_t bricks = p->slots * 1024 * sizeof(float);
   size_t all = bricks + p->tab_entries * 4 + (p->occ_words + p->lbits_words + 2 * p->cbits_words + p->fbits_words) * 4 + p->cap_blocks * 4 + ((p->slots + 3) & ~(size_t)3) +
                p->cap_nodes * (2 * 8 * 4 + 4 + 1) + 2 * (m.cap_keys + 1) * 8 + se_hip_pipeline::kIn * px * 4 + 2 * px * 3 * 4;
+  all += p->sort_cap * sizeof(uint32_t) + p->sort_tmp_bytes;   // (sort_block_list: allocated at the first sort)
   out[0] = m.dense ? 1 : 0; out[1] = (int64_t)p->slots; out[2] = (int64_t)bricks; out[3] = (int64_t)all;
   return SE_HIP_OK;
 }
