@@ -2167,7 +2167,8 @@ __device__ __forceinline__ void se_cast_ray_of_pooled(const DevMap& m, const Ray
 // (r06, the same idea the other way round, measured and dropped: once a batch has met an observed voxel, the following samples taken two / three at a time,
 // each WITH the eight corners of its cell in the batch's own round trip, back to the wide batch when none of them is observed -- 12 bytes of scratch, identical
 // images, and the fused launch 69.6 -> 128 / 111 us at 512^3, the stress stream 89 -> 180 / 146 us: the lanes of a wave are in the two modes at different
-// times, every trip of the loop then runs both bodies, and a short batch advances its lanes a quarter as far.  profiles/r06q_of_observed_batch_ab.log)
+// times, every trip of the loop then runs both bodies, and a short batch advances its lanes a quarter as far.  With the switch made per wave (short batches
+// while >= 16 / 32 / 40 lanes are inside observed space) 75.9 - 78.7 us: still behind.  profiles/r06q_of_observed_batch_ab.log)
 template <bool STATS, bool O32>
 __device__ __forceinline__ void se_cast_ray_of_lean(const DevMap& m, const RayArgs& a, const FieldConst fc, f3 org, f3 dir, float tnear, float tfar,
                                                     BlkCache& c, float& hx, float& hy, float& hz, float& hw, RayCounters& rc) {
