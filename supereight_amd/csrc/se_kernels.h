@@ -256,6 +256,9 @@ __device__ __forceinline__ void se_scan_flush(const DevMap& m, const AllocArgs& 
     uint32_t e;
     if (DENSE) {
       if (val[k]) continue;                        // exists and is active already
+      // (r06, measured and dropped: the index entries of all the not-yet-active slots fetched together in front of this loop instead of one by one behind the
+      // previous slot's insertion -- stress stream scan 21.4 -> 27.3 us at 512^3: the 64 rays of a wave meet the same new blocks at neighbouring slots, and an
+      // entry read early is still 0 for a block a neighbouring lane inserts one slot earlier, so more lanes go through the insertion path to lose its CAS)
       e = m.tab[m.leaf_off + lin[k]];
     } else {
       e = val[k];
