@@ -77,15 +77,17 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(stats: dict, frames: int, W: int, H: int, voxel_bytes: int) -> dict:
+def algorithmic_bytes(stats: dict, frames: int, W: int, H: int, voxel_bytes: int, value_bytes: int = 0) -> dict:
     """per-launch algorithmic bytes of each kernel (every kernel is launched once per
     frame), from work counts summed over the timed frames.  voxel_bytes = sizeof(voxel) of the
-    reference layout (8 SDF, 16 OFusion)."""
+    reference layout (8 SDF, 16 OFusion).  value_bytes (device-layout figures only): what an interpolation / gradient
+    corner costs when it reads the voxel's x alone (4) -- 0 = a whole voxel, as SURVEY 8(d) counts it."""
     n = max(1, frames)
+    vb = value_bytes or voxel_bytes
     # A_int = N_swept*512*sizeof(voxel)*2 + W*H*4 + N_nodes*8*sizeof(voxel)*2 (every node is swept every frame)
     a_int = stats["swept"] / n * 512 * voxel_bytes * 2 + W * H * 4 + stats["nodes"] * 8 * voxel_bytes * 2
     a_alloc = W * H * 4 + stats["probes"] / n * 4
-    a_ray = W * H * 24 + (stats["gets"] + 8 * stats["interps"] + 32 * stats["grads"]) / n * voxel_bytes
+    a_ray = W * H * 24 + (stats["gets"] * voxel_bytes + (8 * stats["interps"] + 32 * stats["grads"]) * vb) / n
     return {"integrate": a_int, "alloc_scan": a_alloc, "raycast": a_ray}
 
 
@@ -619,10 +621,14 @@ def main():
                 r["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/" + tr[1]
                 # what the memory system really moved per second of this kernel, against the same peak: the caches absorb the rest
                 r["hbm_frac"] = tr[0] / (pk[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            if field != SDF:   # the reference-layout figure flatters OFusion: say what the device really moves
-                db = algorithmic_bytes(st, frames, W, H, 8)
-                r["device_layout_bytes_per_launch"] = db[dom]
-                r["device_layout_frac"] = db[dom] / (pk[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            # the reference-layout figure flatters the device where it stores a voxel in fewer bytes (OFusion: float y instead of double, 8 of 16 B;
+            # SDF since r06: the weight as a byte, 5 of 8 B): say what the device really moves
+            db = algorithmic_bytes(st, frames, W, H, 8 if field != SDF else 5, 0 if field != SDF else 4)
+            if fused:
+                db["raycast"] = db["raycast"] + db["alloc_scan"]
+            r["device_layout_bytes_per_launch"] = db[dom]
+            r["device_layout_frac"] = db[dom] / (pk[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            r["device_layout"] = "SDF voxel = float tsdf + uint8 weight (5 B of the reference's 8)" if field == SDF else "OFusion voxel = float + float (8 B of the reference's 16)"
             return r
 
         st = counts["contract"]

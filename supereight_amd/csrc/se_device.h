@@ -12,6 +12,13 @@
 //              (se_core/include/se/node.hpp:139-144).  SDF: x = tsdf, y = weight.
 //              OFusion: x = log-odds, y = last-update time (the reference stores y as double;
 //              every value it ever holds is a float, so float storage is lossless).
+//              SDF weights (r06) are stored as BYTES: sdf_update leaves y = min(y + 1, maxweight = 100) (kfusion/mapping_impl.hpp:60,
+//              DenseSLAMSystem.cpp:235), an integer in 0 .. 100 in every map this library or the reference produces -- one byte holds it without
+//              loss, and the sweep, which is bound by HBM bandwidth from 1024^3 on, moves 5 bytes per voxel and direction instead of 8.  The y plane
+//              of an SDF brick is 512 bytes at byte offset 2048 of the brick (the float plane's place; DevMap::ybyte, se_ld_y / se_st_y), ordered so
+//              that the eight z slices of one (x, y) column are consecutive bytes -- byte SE_YB(v) = ((v & 63) << 3) | (v >> 6) for voxel v = x + 8y + 64z:
+//              the sweep's lane (x, y) reads and writes its eight weights as ONE 8-byte access, the wave 512 consecutive bytes.  Every
+//              export converts back to float.  A map file whose weights are not such integers is refused by se_hip_load_map.
 //   bpos[]     compact list of allocated blocks: packed position in block units
 //              (x | y<<10 | z<<20); bactive[] the VoxelBlock::active_ flag, indexed by voxel slot.
 //   Voxel slot of a block: pooled mode = its list index (pool of max_blocks bricks behind tab[]);
@@ -61,6 +68,7 @@ struct DevMap {
   float dim;
   float* vx;
   float* vy;
+  int ybyte;                      // 1: the y plane of a brick is 512 bytes (SDF weights), 0: 512 floats (OFusion) -- see the layout note above
   uint32_t* bpos;
   uint8_t* bactive;
   float* nx;
@@ -74,6 +82,18 @@ struct DevMap {
   uint32_t cap_blocks, cap_nodes;
   float init_x, init_y, empty_x;
 };
+
+// byte of voxel v (< 512) within the 512-byte weight plane of an SDF brick
+#define SE_YB(v) ((((v) & 63u) << 3) | ((v) >> 6))
+// y of the voxel at float index vi = slot * SE_BRICK_STRIDE + voxel (voxel < 512) -- for the kernels that are not instantiated per field type
+__device__ __forceinline__ float se_ld_y(const DevMap& m, size_t vi) {
+  if (m.ybyte) return (float)((const uint8_t*)(m.vx + (vi & ~(size_t)(SE_BRICK_STRIDE - 1)) + 512))[SE_YB((uint32_t)vi & 511u)];
+  return m.vx[vi + 512];
+}
+__device__ __forceinline__ void se_st_y(const DevMap& m, size_t vi, float y) {
+  if (m.ybyte) ((uint8_t*)(m.vx + (vi & ~(size_t)(SE_BRICK_STRIDE - 1)) + 512))[SE_YB((uint32_t)vi & 511u)] = (uint8_t)(int)y;
+  else m.vx[vi + 512] = y;
+}
 
 struct f3 { float x, y, z; };
 

@@ -625,6 +625,7 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   if (se_flevel(m) > m.clevel) { p->fbits_words = ((size_t)1 << (3 * se_flevel(m))) / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
   m.vy = m.vx + 512;
+  m.ybyte = cfg->field_type == SE_HIP_FIELD_SDF ? 1 : 0;   // SDF weights are stored as bytes (se_device.h)
   ALLOC(m.bpos, cap * sizeof(uint32_t));
   ALLOC(m.bactive, (slots + 3) & ~(size_t)3);   // whole 32-bit words: se_set_active_once
   ALLOC(m.nx, capn * 8 * sizeof(float));
@@ -1867,7 +1868,8 @@ int se_hip_download_blocks(se_hip_pipeline* p, int32_t* coords, float* x, float*
     for (int plane = 0; plane < 2; ++plane) {
       float* dst = plane ? y : x;
       if (!dst) continue;
-      hipLaunchKernelGGL(k_gather_bricks, dim3(2048), dim3(SE_WG), 0, p->stream, plane ? p->map.vy : p->map.vx, d_slots, n, d_pack);
+      if (plane) hipLaunchKernelGGL(k_gather_bricks_y, dim3(2048), dim3(SE_WG), 0, p->stream, p->map, d_slots, n, d_pack);
+      else hipLaunchKernelGGL(k_gather_bricks, dim3(2048), dim3(SE_WG), 0, p->stream, p->map.vx, d_slots, n, d_pack);
       hipMemcpyAsync(dst, d_pack, n * 512 * sizeof(float), hipMemcpyDeviceToHost, p->stream);
     }
     hipError_t e3 = hipStreamSynchronize(p->stream);
@@ -1997,6 +1999,11 @@ int se_hip_load_map(se_hip_pipeline* p, const char* filename) {
   }
   std::fclose(f);
   if (!okr) return fail(SE_HIP_E_INVALID, "truncated or malformed map file");
+  if (p->map.ybyte) {
+    // SDF weights live in one byte each on the device (se_device.h): what sdf_update produces -- integers up to maxweight = 100 -- fits; anything else is not
+    // a map of this pipeline or of the reference's and is refused rather than rounded
+    for (float w : by) if (!(w >= 0.f && w <= 255.f && w == (float)(int)w)) return fail(SE_HIP_E_INVALID, "map file: a voxel weight is not an integer in 0..255 (SDF weights are stored as bytes)");
+  }
   // node keys straight from the file: level and position must be those of an internal node of THIS tree
   for (unsigned long long kx : keys) {
     const int level = (int)(kx & 0x1FFull);

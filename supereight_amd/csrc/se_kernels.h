@@ -919,13 +919,20 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     const uint32_t slot = block_slot(m, b, bp);
     float* px = m.vx + (size_t)slot * 1024 + lane;
     float* py = px + 512;
+    uint2* pyb = (uint2*)(m.vx + (size_t)slot * 1024 + 512) + lane;        // SDF: the weights are bytes, this lane's eight z slices consecutive (se_device.h)
+    uint2 wy = {0u, 0u};
     float vx[8], vy[8];
     const unsigned char act = m.bactive[slot];
     if (!act && !se_in_frustum(a, bx, by, bz)) continue;
     if (a.stats && lane == 0) ++swept;
     {
 #pragma unroll
-      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; vy[zi] = py[zi * 64]; }
+      for (int zi = 0; zi < 8; ++zi) { vx[zi] = px[zi * 64]; if (OFUSION) vy[zi] = py[zi * 64]; }
+      if (!OFUSION) {
+        wy = *pyb;
+#pragma unroll
+        for (int zi = 0; zi < 8; ++zi) vy[zi] = (float)(((zi < 4 ? wy.x : wy.y) >> (8 * (zi & 3))) & 255u);
+      }
     }
     bool visible = false;
     const int y = by + ly;
@@ -974,7 +981,22 @@ __global__ __launch_bounds__(SE_WG) SE_SWEEP_OCC void k_integrate(DevMap m, cons
     // row changed (wave-uniform test): no extra traffic for untouched rows, no branch per voxel otherwise
 #pragma unroll
     for (int zi = 0; zi < 8; ++zi) {
-      if (__ballot(upd[zi]) != 0ull) { px[zi * 64] = vx[zi]; py[zi * 64] = vy[zi]; }
+      if (__ballot(upd[zi]) != 0ull) {
+        px[zi * 64] = vx[zi];
+        if (OFUSION) py[zi * 64] = vy[zi];
+      }
+    }
+    if (!OFUSION) {
+      // the lane's eight weights go back as they came, in one 8-byte store, if the functor touched any voxel of the block
+      bool u = false;
+#pragma unroll
+      for (int zi = 0; zi < 8; ++zi) u = u || upd[zi];
+      if (__ballot(u) != 0ull) {
+        uint2 o;
+        o.x = (uint32_t)(int)vy[0] | ((uint32_t)(int)vy[1] << 8) | ((uint32_t)(int)vy[2] << 16) | ((uint32_t)(int)vy[3] << 24);
+        o.y = (uint32_t)(int)vy[4] | ((uint32_t)(int)vy[5] << 8) | ((uint32_t)(int)vy[6] << 16) | ((uint32_t)(int)vy[7] << 24);
+        *pyb = o;
+      }
     }
     const bool any = __ballot(visible) != 0ull;
     if (lane == 0) m.bactive[slot] = any ? 1 : 0;  // block->active(is_visible)
@@ -1036,9 +1058,8 @@ __global__ __launch_bounds__(SE_WG) void k_apply_bricks(DevMap m, const unsigned
       const float* sx = bvx + (size_t)i * 512 + lane;
       const float* sy = bvy + (size_t)i * 512 + lane;
       float* dx = m.vx + (size_t)slot * SE_BRICK_STRIDE + lane;
-      float* dy = m.vy + (size_t)slot * SE_BRICK_STRIDE + lane;
 #pragma unroll
-      for (int zi = 0; zi < 8; ++zi) { dx[zi * 64] = sx[zi * 64]; dy[zi * 64] = sy[zi * 64]; }
+      for (int zi = 0; zi < 8; ++zi) { dx[zi * 64] = sx[zi * 64]; se_st_y(m, (size_t)slot * SE_BRICK_STRIDE + lane + zi * 64, sy[zi * 64]); }
     }
   }
 }
@@ -1697,6 +1718,8 @@ template <> struct SeDense<true> {     // byte-offset terms, 32 bit
   static __device__ __forceinline__ idx_t sum(idx_t a, idx_t b, idx_t c) { return a + b + c; }
   static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return *(const float*)((const char*)m.vx + (size_t)i); }
   static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return *(const float*)((const char*)m.vx + (size_t)i + 2048); }
+  // SDF: the weight is a byte, 2048 + voxel bytes into the brick (se_device.h)
+  static __device__ __forceinline__ float ldyb(const DevMap& m, idx_t i) { return (float)*((const uint8_t*)m.vx + (size_t)((i & 0xFFFFF000u) + 2048u + SE_YB((i >> 2) & 511u))); }
 };
 template <> struct SeDense<false> {    // (block sum, local sum) in 32 bit each, widened at the load
   struct idx_t { uint32_t blk, loc; };
@@ -1706,6 +1729,7 @@ template <> struct SeDense<false> {    // (block sum, local sum) in 32 bit each,
   static __device__ __forceinline__ idx_t sum(idx_t a, idx_t b, idx_t c) { return {a.blk + b.blk + c.blk, a.loc + b.loc + c.loc}; }
   static __device__ __forceinline__ float ldx(const DevMap& m, idx_t i) { return m.vx[((size_t)i.blk << 10) | i.loc]; }
   static __device__ __forceinline__ float ldy(const DevMap& m, idx_t i) { return m.vx[(((size_t)i.blk << 10) | i.loc) + 512]; }
+  static __device__ __forceinline__ float ldyb(const DevMap& m, idx_t i) { return (float)*((const uint8_t*)m.vx + (((size_t)i.blk << 12) + 2048u + SE_YB(i.loc))); }
 };
 template <bool O32> struct SeCell { float fx, fy, fz; typename SeDense<O32>::idx_t vi[8]; bool inside; };
 // the interpolation cell of a point given in voxel units (Octree::interp, octree.hpp:541-563): fractions and the eight
@@ -1886,11 +1910,11 @@ __device__ __forceinline__ void se_cast_ray_sdf_lean(const DevMap& m, const RayA
       s0.in = s0.in && ((w0 >> (s0.vi.blk & 31u)) & 1u);
       s1.in = s1.in && ((w1 >> (s1.vi.blk & 31u)) & 1u);
       x0 = fc.init_x; y0 = fc.init_y; x1 = fc.init_x; y1 = fc.init_y;
-      if (s0.in) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); }
-      if (s1.in) { x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
+      if (s0.in) { x0 = A::ldx(m, s0.vi); y0 = A::ldyb(m, s0.vi); }
+      if (s1.in) { x1 = A::ldx(m, s1.vi); y1 = A::ldyb(m, s1.vi); }
      }
     }
-    if (!probed) { x0 = A::ldx(m, s0.vi); y0 = A::ldy(m, s0.vi); x1 = A::ldx(m, s1.vi); y1 = A::ldy(m, s1.vi); }
+    if (!probed) { x0 = A::ldx(m, s0.vi); y0 = A::ldyb(m, s0.vi); x1 = A::ldx(m, s1.vi); y1 = A::ldyb(m, s1.vi); }
     SeCell<O32> cell0;
     float cv0[8];
     bool have0 = false;
@@ -1994,7 +2018,9 @@ __device__ __forceinline__ void se_cast_ray_sdf_pooled(const DevMap& m, const Ra
     const f3 q1 = f3_add(q0, f3_scale(S, dir));
     const SePSample s0 = se_sample_pooled<true>(m, a, q0, pc, unobs), s1 = se_sample_pooled<true>(m, a, q1, pc, unobs);
     const size_t i0 = se_pooled_index(s0), i1 = se_pooled_index(s1);
-    const float x0 = m.vx[i0], y0 = m.vx[i0 + 512], x1 = m.vx[i1], y1 = m.vx[i1 + 512];
+    // (SDF weights are bytes, 2048 + voxel bytes into the brick: se_device.h)
+    const uint8_t* yb = (const uint8_t*)m.vx;
+    const float x0 = m.vx[i0], y0 = (float)yb[((i0 >> 10) << 12) + 2048u + SE_YB((uint32_t)i0 & 511u)], x1 = m.vx[i1], y1 = (float)yb[((i1 >> 10) << 12) + 2048u + SE_YB((uint32_t)i1 & 511u)];
     // (r06) inside the truncation band the interpolation cell of sample 0 rides with the batch, as on the dense grid -- when the cell lies inside sample 0's
     // own brick (no corner on another block: two cells in three), its eight addresses follow from the entry the sample has just looked up.  Same values,
     // same blend as se_interp_generic; one round trip instead of two for the sample that decides the step
@@ -2500,6 +2526,11 @@ __global__ __launch_bounds__(SE_WG) void k_gather_bricks(const float* __restrict
   for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 512; i += (size_t)gridDim.x * SE_WG)
     out[i] = plane[(size_t)slots[i >> 9] * SE_BRICK_STRIDE + (i & 511)];
 }
+// ... the y plane, whatever its storage (se_ld_y)
+__global__ __launch_bounds__(SE_WG) void k_gather_bricks_y(DevMap m, const uint32_t* __restrict__ slots, size_t n, float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 512; i += (size_t)gridDim.x * SE_WG)
+    out[i] = se_ld_y(m, (size_t)slots[i >> 9] * SE_BRICK_STRIDE + (i & 511));
+}
 // se_hip_load_map: values of the octants of a map file -> device planes (the octants were inserted by k_alloc_commit before)
 __global__ __launch_bounds__(SE_WG) void k_load_nodes(DevMap m, const unsigned long long* __restrict__ keys, const float* __restrict__ x, const float* __restrict__ y, size_t n) {
   for (size_t i = blockIdx.x * (size_t)SE_WG + threadIdx.x; i < n * 8; i += (size_t)gridDim.x * SE_WG) {
@@ -2527,7 +2558,7 @@ __global__ __launch_bounds__(SE_WG) void k_load_blocks(DevMap m, const int* __re
     const uint32_t e = m.tab[leaf_index(m, bx, by, bz)];
     if (e == 0u || e == SE_PENDING) continue;
     m.vx[(size_t)(e - 1u) * SE_BRICK_STRIDE + (i & 511)] = x[i];
-    m.vy[(size_t)(e - 1u) * SE_BRICK_STRIDE + (i & 511)] = y[i];
+    se_st_y(m, (size_t)(e - 1u) * SE_BRICK_STRIDE + (i & 511), y[i]);
   }
 }
 // pool initialisation: every voxel / node value starts at voxel_traits<T>::initValue()

@@ -23,7 +23,7 @@ __device__ __forceinline__ void se_get_fine(const DevMap& m, int x, int y, int z
   uint32_t e = m.dense ? block_linear(m, x >> 3, y >> 3, z >> 3) + 1u : m.tab[leaf_index(m, x >> 3, y >> 3, z >> 3)];
   if (e == 0u || e == SE_PENDING) return;
   const size_t vi = (size_t)(e - 1u) * SE_BRICK_STRIDE + (size_t)((x & 7) + ((y & 7) << 3) + ((z & 7) << 6));
-  vx = m.vx[vi]; vy = m.vy[vi];
+  vx = m.vx[vi]; vy = se_ld_y(m, vi);
 }
 
 // compute_intersection (meshing.hpp:45-55): s + (0.0 - v1) * (d - s) / (v2 - v1), coefficient-wise

@@ -108,6 +108,23 @@ def test_hip_load_map_round_trip(tmp_path, field, name, mu, pooled):
     assert (b0[0] == b1[0]).all() and (b0[1].view(np.uint32) == b1[1].view(np.uint32)).all() and (b0[2].view(np.uint32) == b1[2].view(np.uint32)).all()
     v0, n0 = built.vertex_normal(); v1, n1 = loaded.vertex_normal()
     assert (v0.view(np.uint32) == v1.view(np.uint32)).all()
+    if field == SDF:
+        # SDF weights are stored as bytes on the device (integers 0..100 in every map sdf_update produced): a file whose weights are anything else is refused,
+        # not rounded -- and the handle keeps the map it had
+        import struct
+        raw = bytearray(open(pa, "rb").read())
+        i = int(np.flatnonzero((y.reshape(-1) > 0) & (np.abs(x.reshape(-1)) < 0.9))[0])
+        pair = struct.pack("<ff", float(x.reshape(-1)[i]), float(y.reshape(-1)[i]))
+        at = bytes(raw).find(pair)
+        assert at >= 0
+        raw[at + 4:at + 8] = struct.pack("<f", 0.5)
+        bad = str(tmp_path / "bad.bin")
+        open(bad, "wb").write(bytes(raw))
+        before = loaded.blocks()
+        with pytest.raises(SeHipError, match="weight"):
+            loaded.load(bad)
+        after = loaded.blocks()
+        assert (before[0] == after[0]).all() and (before[2].view(np.uint32) == after[2].view(np.uint32)).all()
     # a file for another volume is refused
     other = DenseSLAMPipeline((W, H), 2 * N, DIM, field_type=field)
     with pytest.raises(SeHipError, match="does not match"):
