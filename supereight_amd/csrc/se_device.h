@@ -8,7 +8,7 @@
 //   occ[]      occupancy bit pyramid: one bit per possible octant of every level, Morton order
 //              (the 8 children of an octant share one byte).  It is what the ray traversal walks;
 //              its top levels (37 KB for 512^3) are staged in LDS by the raycast kernel.
-//   vx[], vy[] SoA voxel planes, 512 consecutive floats per block and plane (interleaved per brick: [512 x | 512 y]), voxel index x + 8y + 64z
+//   vx[]       voxel bricks, one 4 KB slot per block: the 512 x values (floats), then the 512 y values (OFusion: floats; SDF: bytes, see below), voxel index x + 8y + 64z
 //              (se_core/include/se/node.hpp:139-144).  SDF: x = tsdf, y = weight.
 //              OFusion: x = log-odds, y = last-update time (the reference stores y as double;
 //              every value it ever holds is a float, so float storage is lossless).
@@ -35,7 +35,7 @@
 #include <stdint.h>
 
 #define SE_PENDING 0xFFFFFFFFu
-// Floats from one brick to the next: one array of 4 KB bricks [512 x | 512 y], vy = vx + 512 -- a voxel's two values share a 4 KB page
+// Floats from one brick to the next: one array of 4 KB bricks [512 x | y plane at float 512 = byte 2048] -- a voxel's two values share a 4 KB page
 // (one address translation per get() instead of two; dense maps scatter bricks over 8 / 64 GiB), see DESIGN.md 3.  The lean march paths
 // (SeDense, se_pooled_index) spell the layout out as shifts: 4 096 bytes per brick, y plane 2 048 bytes behind x.
 #define SE_BRICK_STRIDE 1024
@@ -66,8 +66,7 @@ struct DevMap {
   int dense;                      // 1: voxel slot of a block = its linear grid index (no look-up needed to address voxels)
   uint32_t leaf_off;              // = off[leaf_level]; kept separately so that hot kernels never index off[] dynamically
   float dim;
-  float* vx;
-  float* vy;
+  float* vx;                      // the bricks: 1024 floats (4 KB) per slot, x plane first (layout note above)
   int ybyte;                      // 1: the y plane of a brick is 512 bytes (SDF weights), 0: 512 floats (OFusion) -- see the layout note above
   uint32_t* bpos;
   uint8_t* bactive;

@@ -624,7 +624,6 @@ int se_hip_create(const se_hip_config* cfg, se_hip_pipeline** out) {
   // the level-min(leaf, 6) grid, cells of dim / 64 (7.5 cm at 4.8 m): second stage of the beam start, OFusion leap
   if (se_flevel(m) > m.clevel) { p->fbits_words = ((size_t)1 << (3 * se_flevel(m))) / 32; ALLOC(m.fbits, p->fbits_words * sizeof(uint32_t)); }
   ALLOC(m.vx, slots * 1024 * sizeof(float));   // [512 x | 512 y] per brick
-  m.vy = m.vx + 512;
   m.ybyte = cfg->field_type == SE_HIP_FIELD_SDF ? 1 : 0;   // SDF weights are stored as bytes (se_device.h)
   ALLOC(m.bpos, cap * sizeof(uint32_t));
   ALLOC(m.bactive, (slots + 3) & ~(size_t)3);   // whole 32-bit words: se_set_active_once
