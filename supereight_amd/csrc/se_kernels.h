@@ -709,7 +709,8 @@ __device__ __forceinline__ int se_bspline_index(float t) {
 //   * diff / mu: diff is +0 or at least 2^-38 in magnitude (a difference of two floats, one of them >= 1e-4, times a factor >= 1); the
 //     quotient is only looked at through fminf(1, .), which maps every value >= 1, +inf and NaN (an overflowed q0) to 1, and only when
 //     diff > -mu.
-// The weighted average (y x + sdf) / (y + 1) keeps the compiler's division: its operands are stored voxel values nobody bounds.
+// The weighted average (y x + sdf) / (y + 1) keeps the compiler's division: its numerator is a stored voxel value nobody bounds, and its divisor -- an integer
+// in 1 .. 256 since the weights are bytes (r06) -- is a different one per voxel: there is no reciprocal to share.
 struct SeRcp { float nd, r1; };   // -d, and the once-refined reciprocal of d
 __device__ __forceinline__ SeRcp se_rcp_refined(float d) {
   const float r0 = __builtin_amdgcn_rcpf(d);
